@@ -1,0 +1,438 @@
+/*
+ * qldpc_oracle.c -- CPU ORACLE (test infrastructure only; see qldpc_oracle.h).
+ *
+ * Restates, in scalar float32 and in the same operation order, the AFF3CT v2.3.5 decoder that
+ * the reference harness instantiates (AFF3CT itself is an un-vendored third-party dependency:
+ * MP/lib/.gitkeep, MP/ci/build-linux-macos.sh:50,56).  Each function cites the reference call
+ * site whose behaviour it follows and the AFF3CT module it restates.
+ */
+#include "qldpc_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+struct orc_graph {
+    int N, M, E;
+    int *vn_ptr;    /* [N+1] VN-major edge ranges (AFF3CT H.get_row_to_cols())                */
+    int *vn_chk;    /* [E]   check of each VN-major edge, in AFF3CT branch order               */
+    int *cn_ptr;    /* [M+1] CN-major edge ranges (AFF3CT H.get_col_to_rows())                */
+    int *cn_var;    /* [E]   VN of each CN-major edge, in add_connection() order              */
+    int *transpose; /* [E]   CN-major edge k -> VN-major edge id (Decoder_LDPC_BP_flooding ctor) */
+    int max_dc, max_dv;
+};
+
+/* ------------------------------------------------------------------ graph ---------------- */
+
+/*
+ * AFF3CT tools::Sparse_matrix::add_connection(row=VN, col=CN) appends CN to row_to_cols[VN] and
+ * VN to col_to_rows[CN]; H is held with rows = variable nodes (BS/src/main.cpp:178 uses
+ * H.get_cols_max_degree() as the max CN degree).  The flooding decoder's `transpose` gives the
+ * k-th CN-major edge the next free VN-major slot of its variable node, visiting CNs in ascending
+ * order -- so a VN's slots are in ascending-check order of that traversal.
+ */
+orc_graph *orc_graph_from_edges(int N, int M, int E, const int *var, const int *chk)
+{
+    if (N <= 0 || M <= 0 || E <= 0 || !var || !chk) return NULL;
+    orc_graph *g = (orc_graph *)calloc(1, sizeof(*g));
+    g->N = N; g->M = M; g->E = E;
+    g->vn_ptr = (int *)calloc((size_t)N + 1, sizeof(int));
+    g->cn_ptr = (int *)calloc((size_t)M + 1, sizeof(int));
+    g->vn_chk = (int *)malloc((size_t)E * sizeof(int));
+    g->cn_var = (int *)malloc((size_t)E * sizeof(int));
+    g->transpose = (int *)malloc((size_t)E * sizeof(int));
+    for (int e = 0; e < E; e++) {
+        if (var[e] < 0 || var[e] >= N || chk[e] < 0 || chk[e] >= M) { orc_graph_free(g); return NULL; }
+        g->vn_ptr[var[e] + 1]++;
+        g->cn_ptr[chk[e] + 1]++;
+    }
+    for (int v = 0; v < N; v++) { if (g->vn_ptr[v + 1] > g->max_dv) g->max_dv = g->vn_ptr[v + 1]; g->vn_ptr[v + 1] += g->vn_ptr[v]; }
+    for (int c = 0; c < M; c++) { if (g->cn_ptr[c + 1] > g->max_dc) g->max_dc = g->cn_ptr[c + 1]; g->cn_ptr[c + 1] += g->cn_ptr[c]; }
+    int *fill = (int *)calloc((size_t)M, sizeof(int));
+    for (int e = 0; e < E; e++) { int c = chk[e]; g->cn_var[g->cn_ptr[c] + fill[c]++] = var[e]; }
+    free(fill);
+    int *conn = (int *)calloc((size_t)N, sizeof(int));
+    for (int c = 0, k = 0; c < M; c++)
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++, k++) {
+            int v = g->cn_var[j];
+            int slot = g->vn_ptr[v] + conn[v]++;
+            g->transpose[k] = slot;
+            g->vn_chk[slot] = c;
+        }
+    free(conn);
+    return g;
+}
+
+void orc_graph_free(orc_graph *g)
+{
+    if (!g) return;
+    free(g->vn_ptr); free(g->vn_chk); free(g->cn_ptr); free(g->cn_var); free(g->transpose); free(g);
+}
+int orc_graph_N(const orc_graph *g) { return g->N; }
+int orc_graph_M(const orc_graph *g) { return g->M; }
+int orc_graph_E(const orc_graph *g) { return g->E; }
+int orc_graph_max_cn_degree(const orc_graph *g) { return g->max_dc; }
+int orc_graph_max_vn_degree(const orc_graph *g) { return g->max_dv; }
+void orc_graph_export(const orc_graph *g, int *cn_ptr, int *cn_var, int *vn_ptr, int *vn_chk, int *transpose)
+{
+    if (cn_ptr) memcpy(cn_ptr, g->cn_ptr, sizeof(int) * ((size_t)g->M + 1));
+    if (cn_var) memcpy(cn_var, g->cn_var, sizeof(int) * (size_t)g->E);
+    if (vn_ptr) memcpy(vn_ptr, g->vn_ptr, sizeof(int) * ((size_t)g->N + 1));
+    if (vn_chk) memcpy(vn_chk, g->vn_chk, sizeof(int) * (size_t)g->E);
+    if (transpose) memcpy(transpose, g->transpose, sizeof(int) * (size_t)g->E);
+}
+
+/*
+ * MacKay alist as read by tools::LDPC_matrix_handler::read (VAR/main.cpp (alist-v1.0.1):324,338):
+ * line 1 "N M" (N listed first = variable nodes), line 2 max degrees, line 3 VN degrees, line 4 CN
+ * degrees, then N per-VN lists (1-based check ids, 0 = padding) which drive add_connection(), then
+ * M per-CN lists (only cross-checked).
+ */
+orc_graph *orc_graph_from_alist(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    int N, M, dvmax, dcmax;
+    if (fscanf(f, "%d %d %d %d", &N, &M, &dvmax, &dcmax) != 4 || N <= 0 || M <= 0) { fclose(f); return NULL; }
+    int *dv = (int *)malloc(sizeof(int) * (size_t)N), *dc = (int *)malloc(sizeof(int) * (size_t)M);
+    long E = 0;
+    for (int v = 0; v < N; v++) { if (fscanf(f, "%d", &dv[v]) != 1) goto bad; E += dv[v]; }
+    for (int c = 0; c < M; c++) { if (fscanf(f, "%d", &dc[c]) != 1) goto bad; }
+    {
+        int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
+        long e = 0;
+        int ok = 1;
+        /* Each VN line holds dv[v] entries, optionally zero-padded up to dvmax on the same line.
+         * Read line-wise so both padded and unpadded files parse. */
+        int ch;
+        while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+        char *line = NULL; size_t cap = 0;
+        for (int v = 0; v < N && ok; v++) {
+            if (getline(&line, &cap, f) < 0) { ok = 0; break; }
+            char *p = line; int got = 0;
+            for (;;) {
+                char *end; long x = strtol(p, &end, 10);
+                if (end == p) break;
+                p = end;
+                if (x > 0) { if (e >= E || x > M) { ok = 0; break; } var[e] = v; chk[e] = (int)x - 1; e++; got++; }
+            }
+            if (got != dv[v]) ok = 0;
+        }
+        /* cross-check the CN part */
+        long e2 = 0;
+        for (int c = 0; c < M && ok; c++) {
+            if (getline(&line, &cap, f) < 0) { ok = 0; break; }
+            char *p = line; int got = 0;
+            for (;;) { char *end; long x = strtol(p, &end, 10); if (end == p) break; p = end; if (x > 0) { got++; e2++; } }
+            if (got != dc[c]) ok = 0;
+        }
+        free(line);
+        orc_graph *g = (ok && e == E && e2 == E) ? orc_graph_from_edges(N, M, (int)E, var, chk) : NULL;
+        free(var); free(chk); free(dv); free(dc); fclose(f);
+        return g;
+    }
+bad:
+    free(dv); free(dc); fclose(f);
+    return NULL;
+}
+
+/*
+ * AFF3CT .qc (EC/ldpc_examples/README.md:7, EC/README_LDPC.md:494-498): header "cols rows Z",
+ * then `rows` lines of `cols` entries; -1 = zero block, s >= 0 = ZxZ identity right-shifted by s
+ * (block row r has its 1 in block column (r + s) mod Z -- ML/mul_sh.m:6-10, ML/check_cword.m).
+ * Connections are added block by block, row-block major, z ascending.
+ */
+orc_graph *orc_graph_from_qc(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    int nb, mb, Z;
+    if (fscanf(f, "%d %d %d", &nb, &mb, &Z) != 3 || nb <= 0 || mb <= 0 || Z <= 0) { fclose(f); return NULL; }
+    int *B = (int *)malloc(sizeof(int) * (size_t)nb * mb);
+    long blocks = 0;
+    for (int i = 0; i < mb * nb; i++) { if (fscanf(f, "%d", &B[i]) != 1) { free(B); fclose(f); return NULL; } if (B[i] >= 0) blocks++; }
+    fclose(f);
+    long E = blocks * Z;
+    int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
+    long e = 0;
+    for (int i = 0; i < mb; i++)
+        for (int j = 0; j < nb; j++) {
+            int s = B[i * nb + j];
+            if (s < 0) continue;
+            for (int z = 0; z < Z; z++) { chk[e] = i * Z + z; var[e] = j * Z + (z + s) % Z; e++; }
+        }
+    orc_graph *g = orc_graph_from_edges(nb * Z, mb * Z, (int)E, var, chk);
+    free(var); free(chk); free(B);
+    return g;
+}
+
+int orc_syndrome(const orc_graph *g, const int *x, int *s)
+{
+    int w = 0;
+    for (int c = 0; c < g->M; c++) {
+        int p = 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) p ^= (x[g->cn_var[j]] & 1);
+        if (s) s[c] = p;
+        w += p;
+    }
+    return w;
+}
+
+/* ------------------------------------------------------------- update rules -------------- */
+
+static inline int sgnbit(float x) { return signbit(x) ? -1 : 0; }   /* AFF3CT: std::signbit(v) ? -1 : 0 */
+static inline float csign(float mag, int s) { return copysignf(mag, s ? -1.0f : 1.0f); }
+
+/* tools::min_star / min_star_linear2 (AFF3CT Tools/Math/utils.h) -- parity unpinned */
+/* std::min / std::max semantics: min(a,b) = (b < a) ? b : a ; max(a,b) = (a < b) ? b : a */
+static inline float f_min(float a, float b) { return (b < a) ? b : a; }
+static inline float f_max(float a, float b) { return (a < b) ? b : a; }
+static inline float f_min_star(float a, float b)
+{
+    return (a < b ? a : b) + logf(1.0f + expf(-(a + b))) - logf(1.0f + expf(-fabsf(a - b)));
+}
+static inline float corr_l2(float x) { float t = 0.6f - 0.24f * fabsf(x); return t > 0.0f ? t : 0.0f; }
+static inline float f_min_star_l2(float a, float b)
+{
+    float r = (a < b ? a : b) + corr_l2(a + b) - corr_l2(a - b);
+    return r > 0.0f ? r : 0.0f;
+}
+
+/*
+ * One check node: in[0..deg) are the incoming var->chk messages in col_to_rows order, out[] the
+ * outgoing chk->var messages.  Restates tools::Update_rule_{MS,OMS,NMS,SPA,LSPA,AMS}
+ * (begin_chk_node_in / compute_chk_node_in xdeg / end_chk_node_in / compute_chk_node_out xdeg),
+ * selected at VAR/main.cpp (alist-v1.0.1):203-218 and BS/src/main.cpp:193.
+ */
+static void cn_update(int rule, float param, int deg, const float *in, float *out, float *scratch)
+{
+    int sign = 0;
+    switch (rule) {
+    case ORC_RULE_MS:
+    case ORC_RULE_OMS:
+    case ORC_RULE_NMS: {
+        float min1 = FLT_MAX, min2 = FLT_MAX;
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            sign ^= sgnbit(in[i]);
+            min2 = f_min(min2, f_max(a, min1));   /* min2 = min(min2, max(var_abs, min1)) */
+            min1 = f_min(min1, a);                /* min1 = min(min1, var_abs)            */
+        }
+        float cst1, cst2;
+        if (rule == ORC_RULE_MS)       { cst1 = f_max(0.0f, min2);         cst2 = f_max(0.0f, min1); }
+        else if (rule == ORC_RULE_OMS) { cst1 = f_max(0.0f, min2 - param); cst2 = f_max(0.0f, min1 - param); }
+        else                           { cst1 = min2 * param;              cst2 = min1 * param; }
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            const float r = (a == min1) ? cst1 : cst2;
+            out[i] = csign(r, sign ^ sgnbit(in[i]));
+        }
+        break;
+    }
+    case ORC_RULE_SPA: {
+        float product = 1.0f;
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            const float r = tanhf(a * 0.5f);
+            sign ^= sgnbit(in[i]);
+            product *= r;
+            scratch[i] = r;
+        }
+        for (int i = 0; i < deg; i++) {
+            float t = product / scratch[i];
+            t = (t < 1.0f) ? t : 1.0f - FLT_EPSILON;
+            const float r = 2.0f * atanhf(t);
+            out[i] = csign(r, sign ^ sgnbit(in[i]));
+        }
+        break;
+    }
+    case ORC_RULE_LSPA: {
+        float sum = 0.0f;
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            const float t = tanhf(a * 0.5f);
+            const float r = (t != 0.0f) ? logf(t) : FLT_MIN;
+            sign ^= sgnbit(in[i]);
+            sum += r;
+            scratch[i] = r;
+        }
+        for (int i = 0; i < deg; i++) {
+            float t = sum - scratch[i];
+            t = (t != 0.0f) ? expf(t) : 1.0f - FLT_EPSILON;
+            const float r = 2.0f * atanhf(t);
+            out[i] = csign(r, sign ^ sgnbit(in[i]));
+        }
+        break;
+    }
+    default: { /* AMS<MIN>: delta = MIN over all |in|, delta_min = MIN over all but the minimum */
+        float min = FLT_MAX, delta_min = FLT_MAX;
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            sign ^= sgnbit(in[i]);
+            float other;
+            if (a < min) { other = min; min = a; } else other = a;
+            if (rule == ORC_RULE_AMS_MIN) delta_min = f_min(delta_min, other);
+            else if (rule == ORC_RULE_AMS_MINSTAR) delta_min = f_min_star(delta_min, other);
+            else delta_min = f_min_star_l2(delta_min, other);
+        }
+        float delta;
+        if (rule == ORC_RULE_AMS_MIN) delta = f_min(delta_min, min);
+        else if (rule == ORC_RULE_AMS_MINSTAR) delta = f_min_star(delta_min, min);
+        else delta = f_min_star_l2(delta_min, min);
+        delta = f_max(0.0f, delta);
+        delta_min = f_max(0.0f, delta_min);
+        for (int i = 0; i < deg; i++) {
+            const float a = fabsf(in[i]);
+            const float r = (a == min) ? delta_min : delta;
+            out[i] = csign(r, sign ^ sgnbit(in[i]));
+        }
+        break;
+    }
+    }
+}
+
+/* ------------------------------------------------------------- syndrome ------------------ */
+
+/* Decoder_LDPC_BP::check_syndrome_soft: XOR of signbit(post) over each check's VNs. */
+static int syndrome_is_zero(const orc_graph *g, const float *post)
+{
+    for (int c = 0; c < g->M; c++) {
+        int s = 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) s ^= sgnbit(post[g->cn_var[j]]);
+        if (s) return 0;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------- flooding ------------------ */
+
+/*
+ * module::Decoder_LDPC_BP_flooding<B,Q,Rule>::_decode_siho for one frame after reset()
+ * (BS/src/main.cpp:365,389).  Per iteration:
+ *   _initialize_var_to_chk : tmp = Y[v] + (sum of chk_to_var over the VN's slots, in slot order,
+ *                            starting from 0);  var_to_chk[slot] = tmp - chk_to_var[slot]
+ *   _decode_single_ite     : per CN in order, gather via transpose, rule in/out, scatter
+ *   if enable_syndrome && ite != n_ite-1: post = Y + sum; break when the syndrome has been zero
+ *                            `syndrome_depth` consecutive times
+ * After the loop (no break) post is computed once more.  V = !(post >= 0).
+ */
+static int decode_flooding(const orc_graph *g, int rule, float param, int n_ite, int enable_syndrome,
+                           int syndrome_depth, const float *Y, float *post, float *c2v, float *v2c,
+                           float *in, float *out, float *scratch)
+{
+    const int N = g->N, M = g->M, E = g->E;
+    memset(c2v, 0, sizeof(float) * (size_t)E);   /* _load() with init_flag set by reset() */
+    int cur_depth = 0, ite = 0;
+    for (; ite < n_ite; ite++) {
+        for (int v = 0; v < N; v++) {
+            float sum = 0.0f;
+            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+            const float tmp = Y[v] + sum;
+            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) v2c[e] = tmp - c2v[e];
+        }
+        for (int c = 0; c < M; c++) {
+            const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
+            for (int i = 0; i < deg; i++) in[i] = v2c[g->transpose[b + i]];
+            cn_update(rule, param, deg, in, out, scratch);
+            for (int i = 0; i < deg; i++) c2v[g->transpose[b + i]] = out[i];
+        }
+        if (enable_syndrome && ite != n_ite - 1) {
+            for (int v = 0; v < N; v++) {
+                float sum = 0.0f;
+                for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+                post[v] = Y[v] + sum;
+            }
+            const int z = syndrome_is_zero(g, post);
+            cur_depth = z ? (cur_depth + 1) % syndrome_depth : 0;
+            if (z && cur_depth == 0) { ite++; return ite; }
+        }
+    }
+    for (int v = 0; v < N; v++) {
+        float sum = 0.0f;
+        for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+        post[v] = Y[v] + sum;
+    }
+    return ite;
+}
+
+/* ------------------------------------------------------------- horizontal layered -------- */
+
+/*
+ * module::Decoder_LDPC_BP_horizontal_layered<B,Q,Rule> (VAR/main.cpp (alist-v1.0.1):223-237):
+ * var_nodes = Y; messages = 0; per iteration, per CN in order:
+ *   contributions[i] = var_nodes[v_i] - messages[kr++]; rule in;  messages[kw] = rule out;
+ *   var_nodes[v_i] = contributions[i] + messages[kw++]
+ * then check_syndrome_soft(var_nodes) after EVERY iteration (also the last one).
+ * The same recursion as ML/BPSK_nrldpc_sim.m:29-69 (layer = one check row).
+ */
+static int decode_hlayered(const orc_graph *g, int rule, float param, int n_ite, int enable_syndrome,
+                           int syndrome_depth, const float *Y, float *post, float *msg,
+                           float *in, float *out, float *scratch)
+{
+    const int N = g->N, M = g->M, E = g->E;
+    memcpy(post, Y, sizeof(float) * (size_t)N);
+    memset(msg, 0, sizeof(float) * (size_t)E);
+    int cur_depth = 0, ite = 0;
+    for (; ite < n_ite; ite++) {
+        for (int c = 0; c < M; c++) {
+            const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
+            for (int i = 0; i < deg; i++) in[i] = post[g->cn_var[b + i]] - msg[b + i];
+            cn_update(rule, param, deg, in, out, scratch);
+            for (int i = 0; i < deg; i++) { msg[b + i] = out[i]; post[g->cn_var[b + i]] = in[i] + out[i]; }
+        }
+        if (enable_syndrome) {
+            const int z = syndrome_is_zero(g, post);
+            cur_depth = z ? (cur_depth + 1) % syndrome_depth : 0;
+            if (z && cur_depth == 0) { ite++; return ite; }
+        }
+    }
+    return ite;
+}
+
+/* ------------------------------------------------------------- entry --------------------- */
+
+int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int n_ite,
+               int enable_syndrome, int syndrome_depth, const float *Y_N, int n_frames,
+               float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
+{
+    if (!g || !Y_N || n_frames < 0 || n_ite < 0) return -1;
+    if (rule < ORC_RULE_MS || rule > ORC_RULE_AMS_MINSTAR) return -2;
+    if (schedule != ORC_SCHED_FLOODING && schedule != ORC_SCHED_HLAYERED) return -3;
+    if (syndrome_depth < 1) syndrome_depth = 1;
+    const int N = g->N, E = g->E;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        float *post = (float *)malloc(sizeof(float) * (size_t)N);
+        float *a = (float *)malloc(sizeof(float) * (size_t)E);
+        float *b = (float *)malloc(sizeof(float) * (size_t)E);
+        float *in = (float *)malloc(sizeof(float) * (size_t)(g->max_dc + 1) * 3);
+        float *out = in + g->max_dc + 1, *scratch = out + g->max_dc + 1;
+        int *hd = (int *)malloc(sizeof(int) * (size_t)N);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int f = 0; f < n_frames; f++) {
+            const float *Y = Y_N + (size_t)f * N;
+            int it;
+            if (schedule == ORC_SCHED_FLOODING)
+                it = decode_flooding(g, rule, rule_param, n_ite, enable_syndrome, syndrome_depth, Y, post, a, b, in, out, scratch);
+            else
+                it = decode_hlayered(g, rule, rule_param, n_ite, enable_syndrome, syndrome_depth, Y, post, a, in, out, scratch);
+            for (int v = 0; v < N; v++) hd[v] = !(post[v] >= 0.0f);   /* V_K[i] = !(post[k] >= 0) */
+            if (post_out) memcpy(post_out + (size_t)f * N, post, sizeof(float) * (size_t)N);
+            if (hard) memcpy(hard + (size_t)f * N, hd, sizeof(int) * (size_t)N);
+            if (iters) iters[f] = it;
+            if (synd_ok) synd_ok[f] = (orc_syndrome(g, hd, NULL) == 0);
+        }
+        free(post); free(a); free(b); free(in); free(hd);
+    }
+    return 0;
+}
