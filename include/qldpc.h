@@ -1,0 +1,207 @@
+/*
+ * qldpc.h -- C ABI of libqldpc.so: MI355X (gfx950) batched LDPC belief-propagation reconciliation.
+ *
+ * This is the drop-in boundary for the LDPC path of JarryChou/qcrypto-ldpc.  Plain C types only
+ * (pointers, sizes, ints, floats); no C++/torch types.  Every entry point returns QLDPC_OK (0) or a
+ * negative qldpc_status; nothing throws.  One decoder instance is not re-entrant (neither is an
+ * AFF3CT module); use one per host thread / stream.
+ *
+ * Reference interfaces replaced (paths under /root/reference/errorcorrection/, BS =
+ * ldpc_examples/my_project_with_aff3ct/examples/bootstrap, VAR = BS/src/variants (copy out as main.cpp to use)):
+ *
+ *   qldpc_code_from_alist / _from_qc      tools::LDPC_matrix_handler::read_matrix_size / read
+ *                                         VAR/main.cpp (alist-v1.0.1):324,338 ; VAR/main.cpp (qc):145
+ *   qldpc_code_ira                        tools::build_dvbs2 + tools::build_H        BS/src/main.cpp:175-176
+ *                                         (DVB-S2 tables are AFF3CT built-ins and not in the tree; this
+ *                                         builds a DVB-like IRA code of any (N,K) instead)
+ *   qldpc_code_max_cn_degree              H.get_cols_max_degree()                    BS/src/main.cpp:178
+ *   qldpc_decoder_create                  module::Decoder_LDPC_BP_flooding<B,Q,Rule>(K, N, n_ite, H, info_bits_pos,
+ *                                         rule(param), enable_syndrome, syndrome_depth, n_frames)
+ *                                         BS/src/main.cpp:193 ; VAR/main.cpp (alist-v1.0.1):179-256
+ *   qldpc_decode_siho                     decoder->decode_siho(LLRs, dec_bits)       BS/src/main.cpp:365
+ *   qldpc_decoder_reset                   (*(m.decoder)).reset()                     BS/src/main.cpp:389
+ *   qldpc_llr_from_ber, QLDPC_CONFIRMED_BIT_LLR   LLR(BER), CONFIRMED_BIT_LLR        BS/src/main.cpp:19-20
+ *   qldpc_load_bits_*  (frame formation)  modem->demodulate + parity pinning + puncturing
+ *                                         BS/src/main.cpp:348-362 ; VAR/main.cpp (5g-qc):514-531
+ *   qldpc_encoder_* / qldpc_encode_*      m.encoder->encode(ref_bits, enc_bits)      BS/src/main.cpp:341 ;
+ *                                         Encoder_LDPC_from_H(K,N,H,"IDENTITY",...)  VAR/main.cpp (alist-v1.0.1):142-145
+ *   qldpc_min_code_rate, qldpc_parity_bits_to_punct   min_cr(), parity_bits_to_punct()   BS/src/main.cpp:23-34
+ *   packed-bit layout (bit i <-> word[i/32] & (1u << (31 - i%32)))                  subcomponents/helpers.h:65-70
+ */
+#ifndef QLDPC_H
+#define QLDPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QLDPC_VERSION 100
+
+typedef enum qldpc_status {
+    QLDPC_OK = 0,
+    QLDPC_EINVAL = -1,       /* bad argument                                                    */
+    QLDPC_ENOMEM = -2,       /* host or device allocation failed                                */
+    QLDPC_EIO = -3,          /* matrix file unreadable / malformed                              */
+    QLDPC_EHIP = -4,         /* a HIP call failed (qldpc_last_error() has the text)             */
+    QLDPC_ENODEV = -5,       /* no gfx950-capable device visible                                */
+    QLDPC_ESIZE = -6,        /* size mismatch (AFF3CT throws tools::length_error here)          */
+    QLDPC_EUNSUPPORTED = -7, /* valid request this build does not implement                     */
+    QLDPC_ESTATE = -8        /* call sequence error (e.g. run before load)                      */
+} qldpc_status;
+
+/* tools::Update_rule_* selected at VAR/main.cpp (alist-v1.0.1):203-218 */
+typedef enum qldpc_rule {
+    QLDPC_RULE_MS = 0,            /* Update_rule_MS                                  */
+    QLDPC_RULE_OMS = 1,           /* Update_rule_OMS(offset)        param = offset   */
+    QLDPC_RULE_NMS = 2,           /* Update_rule_NMS(norm_factor)   param = factor   */
+    QLDPC_RULE_SPA = 3,           /* Update_rule_SPA(max_CN_degree)                  */
+    QLDPC_RULE_LSPA = 4,          /* Update_rule_LSPA                                */
+    QLDPC_RULE_AMS_MIN = 5,       /* Update_rule_AMS<min>                            */
+    QLDPC_RULE_AMS_MINSTAR_L2 = 6,/* Update_rule_AMS<min_star_linear2>               */
+    QLDPC_RULE_AMS_MINSTAR = 7    /* Update_rule_AMS<min_star>                       */
+} qldpc_rule;
+
+/* Decoder_LDPC_BP_{flooding,horizontal_layered}; VAR/main.cpp (alist-v1.0.1):203-237 */
+typedef enum qldpc_schedule {
+    QLDPC_SCHED_FLOODING = 0,
+    QLDPC_SCHED_HLAYERED = 1      /* horizontal layered, checks visited in the code's layer order */
+} qldpc_schedule;
+
+/* Per-VN class for QKD frame formation (BS/src/main.cpp:348-362) */
+enum {
+    QLDPC_VN_CHANNEL = 0,   /* sifted-key bit seen through the BSC:  LLR = (1-2y) ln((1-p)/p)      */
+    QLDPC_VN_PINNED = 1,    /* bit disclosed by Alice (parity):      LLR = y ? -23.02585 : +23.02585 */
+    QLDPC_VN_PUNCTURED = 2  /* punctured parity VN:                  LLR = 0                         */
+};
+
+#define QLDPC_CONFIRMED_BIT_LLR 23.025850929840455f /* -log(1e-10 / (1 - 1e-10)), BS/src/main.cpp:19 */
+
+typedef struct qldpc_code qldpc_code;
+typedef struct qldpc_decoder qldpc_decoder;
+typedef struct qldpc_encoder qldpc_encoder;
+
+/* ------------------------------------------------------------------ library ------------------ */
+int qldpc_version(void);
+const char *qldpc_strerror(int status);
+const char *qldpc_last_error(void);           /* thread-local text of the last failure          */
+int qldpc_device_count(void);                 /* HIP devices visible (0 on a CPU-only host)     */
+
+/* ------------------------------------------------------------------ scalar helpers ----------- */
+float qldpc_llr_from_ber(float ber);                          /* LLR(BER) = -log(p/(1-p)) in double, BS/src/main.cpp:20 */
+float qldpc_bsc_llr(float ber);                               /* Modem_OOK_BSC: logf((1-p)/p) in float, BS/src/main.cpp:317,348 */
+float qldpc_binary_entropy(float q);                          /* h(q), BS/src/main.cpp:23-26       */
+float qldpc_min_code_rate(float qber, float efficiency);      /* 1/(1+f h(q))... BS/src/main.cpp:29 */
+int qldpc_parity_bits_to_punct(int N, int K, float target_cr);/* BS/src/main.cpp:34                */
+
+/* ------------------------------------------------------------------ code (H matrix) ---------- */
+int qldpc_code_from_alist(const char *path, qldpc_code **out);
+int qldpc_code_from_qc(const char *path, qldpc_code **out);
+/* (var[e], chk[e]) in add_connection order: that order is each check's edge order. */
+int qldpc_code_from_edges(int N, int M, int E, const int *var, const int *chk, qldpc_code **out);
+/*
+ * DVB-like IRA code: info VNs 0..K-1 (the first hi_frac*K have degree dv_hi, the rest dv_lo),
+ * parity VNs K..N-1 on a dual diagonal, every check the same number of info edges, seeded
+ * socket shuffle.  (N=65536,K=52429,hi_frac=.125,dv_hi=11,dv_lo=3,seed=7) is BASELINE config 2.
+ */
+int qldpc_code_ira(int N, int K, float hi_frac, int dv_hi, int dv_lo, uint64_t seed, qldpc_code **out);
+void qldpc_code_free(qldpc_code *code);
+int qldpc_code_n(const qldpc_code *code);
+int qldpc_code_m(const qldpc_code *code);
+int qldpc_code_e(const qldpc_code *code);
+int qldpc_code_max_cn_degree(const qldpc_code *code);
+int qldpc_code_max_vn_degree(const qldpc_code *code);
+int qldpc_code_is_ira(const qldpc_code *code);     /* 1 if parity VNs K..N-1 form a dual diagonal */
+/* CN-major edge list, E entries each (pass NULL to skip one). */
+int qldpc_code_export_edges(const qldpc_code *code, int *var, int *chk);
+/* Number of conflict-free layers of the horizontal-layered order, and that order (M entries). */
+int qldpc_code_layer_count(const qldpc_code *code);
+int qldpc_code_layer_order(const qldpc_code *code, int *check_order, int *layer_ptr /* layers+1 */);
+/* H x over GF(2) for one host word of 0/1 ints; returns the syndrome weight (>= 0) or a status. */
+int qldpc_code_syndrome_host(const qldpc_code *code, const int *x, int *s);
+
+/* ------------------------------------------------------------------ decoder ------------------ */
+typedef struct qldpc_decoder_cfg {
+    int schedule;        /* qldpc_schedule                                                       */
+    int rule;            /* qldpc_rule                                                           */
+    float rule_param;    /* OMS offset / NMS factor                                              */
+    int n_ite;           /* maximum BP iterations (AFF3CT n_ite)                                 */
+    int enable_syndrome; /* stop a frame once its syndrome is zero (AFF3CT enable_syndrome)      */
+    int syndrome_depth;  /* consecutive zero syndromes required (AFF3CT syndrome_depth), >= 1    */
+    int max_frames;      /* capacity: frames decoded concurrently in one call (AFF3CT n_frames)  */
+    int device;          /* HIP device ordinal                                                   */
+    int frames_per_lane; /* 0 = auto; 1, 2 or 4 frames per wavefront lane (64/128/256-frame groups) */
+    int reserved[7];     /* must be zero                                                         */
+} qldpc_decoder_cfg;
+
+void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);
+/* info_bits_pos may be NULL (= 0..K-1, the harness default VAR/main.cpp (alist-v1.0.1):147-159). */
+int qldpc_decoder_create(const qldpc_code *code, int K, const int *info_bits_pos,
+                         const qldpc_decoder_cfg *cfg, qldpc_decoder **out);
+void qldpc_decoder_free(qldpc_decoder *dec);
+/* hipStream_t to launch on (NULL = the null stream).  All *_dev calls are asynchronous on it. */
+int qldpc_decoder_set_stream(qldpc_decoder *dec, void *hip_stream);
+int qldpc_decoder_reset(qldpc_decoder *dec);
+size_t qldpc_decoder_device_bytes(const qldpc_decoder *dec);   /* HBM held by this decoder        */
+
+/* AFF3CT mirror, host pointers: Y_N[n_frames][N] -> V_K[n_frames][K] (one int per bit). Synchronous. */
+int qldpc_decode_siho(qldpc_decoder *dec, const float *Y_N, int *V_K, int n_frames);
+
+/* ---- staged, HBM-resident path.  d_* are device pointers on the decoder's device. ----------- */
+/* load: channel LLRs [n_frames][N] float (frame-major, as decode_siho takes them). */
+int qldpc_load_llr_dev(qldpc_decoder *dec, const float *d_llr, int n_frames);
+/*
+ * load: QKD-native frame formation on the device.  d_bits[n_frames][ceil(N/32)] packed MSB-first
+ * (helpers.h:65-70): Bob's sifted-key bits at channel VNs, Alice's disclosed bits at pinned VNs.
+ * d_llr_mag[n_frames] = |LLR| of a channel bit of that frame, i.e. qldpc_bsc_llr(estimated QBER)
+ * (ProcessBlock.localError) computed by the host; d_vn_class[N] (NULL = all QLDPC_VN_CHANNEL) is
+ * shared by all frames.
+ */
+int qldpc_load_bits_dev(qldpc_decoder *dec, const uint32_t *d_bits, const float *d_llr_mag,
+                        const uint8_t *d_vn_class, int n_frames);
+/* run the BP iterations on what was loaded. */
+int qldpc_run(qldpc_decoder *dec);
+/* fetch: hard decision of every VN, packed MSB-first, d_out[n_frames][ceil(N/32)]. */
+int qldpc_fetch_packed_dev(qldpc_decoder *dec, uint32_t *d_out);
+/* fetch: V_K[n_frames][K] ints at info_bits_pos (AFF3CT layout). */
+int qldpc_fetch_info_dev(qldpc_decoder *dec, int *d_V_K);
+/* fetch: per-frame iterations executed and 1/0 "syndrome of the hard decision is zero". */
+int qldpc_fetch_status_dev(qldpc_decoder *dec, int *d_iters, int *d_ok);
+/* fetch: a-posteriori LLRs [n_frames][N] (debug / parity tests; costs one extra pass). */
+int qldpc_fetch_post_dev(qldpc_decoder *dec, float *d_post);
+/* block until everything queued on the decoder's stream is done. */
+int qldpc_sync(qldpc_decoder *dec);
+
+/* ---- measurement hooks ---------------------------------------------------------------------- */
+typedef struct qldpc_kernel_stat {
+    char name[32];        /* kernel family: "cn_update", "vn_update", ...                         */
+    uint64_t launches;
+    double total_ms;      /* hipEvent time summed over launches                                   */
+    double alg_bytes;     /* algorithmic bytes summed over launches         */
+} qldpc_kernel_stat;
+/* When on, every kernel launch is bracketed by hipEvents on the decoder's stream. */
+int qldpc_profile_enable(qldpc_decoder *dec, int on);
+/* Sync, fold events into stats; writes up to cap entries, returns the count (or a status). */
+int qldpc_profile_read(qldpc_decoder *dec, qldpc_kernel_stat *out, int cap);
+int qldpc_profile_clear(qldpc_decoder *dec);
+/* Launches actually issued by the last qldpc_run (converged groups make later ones no-ops). */
+int qldpc_last_run_iterations(const qldpc_decoder *dec);
+
+/* ------------------------------------------------------------------ encoder (Alice) ---------- */
+/* method: "IRA" (dual-diagonal accumulate) or "IDENTITY" (GF(2) elimination, any full-rank H). */
+int qldpc_encoder_create(const qldpc_code *code, const char *method, int device, qldpc_encoder **out);
+void qldpc_encoder_free(qldpc_encoder *enc);
+int qldpc_encoder_k(const qldpc_encoder *enc);
+int qldpc_encoder_info_bits_pos(const qldpc_encoder *enc, int *pos /* K */);
+/* host mirror of encoder->encode: U_K[n_frames][K] ints -> X_N[n_frames][N] ints. */
+int qldpc_encode(qldpc_encoder *enc, const int *U_K, int *X_N, int n_frames);
+/* device, packed MSB-first: d_info[n_frames][ceil(K/32)] -> d_cw[n_frames][ceil(N/32)]. */
+int qldpc_encode_packed_dev(qldpc_encoder *enc, const uint32_t *d_info, uint32_t *d_cw, int n_frames,
+                            void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLDPC_H */

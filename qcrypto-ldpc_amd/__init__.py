@@ -1,0 +1,414 @@
+"""qcrypto-ldpc_amd: host-side mirror (Python, ctypes) of the LDPC reconciliation path.
+
+The product is ``libqldpc.so`` (hand-written HIP for gfx950 behind the C ABI of ``include/qldpc.h``).
+This package only binds it: names and argument meaning follow the objects the reference harness
+builds from AFF3CT (``Decoder_LDPC_BP_flooding(K, N, n_ite, H, info_bits_pos, rule, enable_syndrome,
+syndrome_depth, n_frames)``, ``decode_siho``, ``reset``, ``encode`` -- BS/src/main.cpp:172-195,335-393).
+PyTorch appears only as the owner of device buffers / streams handed to the C ABI as raw pointers.
+
+There is NO CPU fallback: if the shared library is missing the import fails loudly.
+
+The directory name has a hyphen, so load it with ``_qldpc_loader.load()`` (repo root) which
+registers it as module ``qcrypto_ldpc_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqldpc.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libqldpc.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+        "`make -C qcrypto-ldpc_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+
+_L = C.CDLL(LIB_PATH)
+
+RULES = {"MS": 0, "OMS": 1, "NMS": 2, "SPA": 3, "LSPA": 4, "AMS_MIN": 5, "AMS_MINSTAR_L2": 6, "AMS_MINSTAR": 7}
+SCHEDULES = {"flooding": 0, "hlayered": 1}
+VN_CHANNEL, VN_PINNED, VN_PUNCTURED = 0, 1, 2
+CONFIRMED_BIT_LLR = 23.025850929840455
+
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class DecoderCfg(C.Structure):
+    _fields_ = [("schedule", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("n_ite", C.c_int),
+                ("enable_syndrome", C.c_int), ("syndrome_depth", C.c_int), ("max_frames", C.c_int),
+                ("device", C.c_int), ("frames_per_lane", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+
+
+def _sig(name, res, args):
+    f = getattr(_L, name)
+    f.restype = res
+    f.argtypes = args
+    return f
+
+
+_sig("qldpc_version", C.c_int, [])
+_sig("qldpc_strerror", C.c_char_p, [C.c_int])
+_sig("qldpc_last_error", C.c_char_p, [])
+_sig("qldpc_device_count", C.c_int, [])
+_sig("qldpc_llr_from_ber", C.c_float, [C.c_float])
+_sig("qldpc_bsc_llr", C.c_float, [C.c_float])
+_sig("qldpc_binary_entropy", C.c_float, [C.c_float])
+_sig("qldpc_min_code_rate", C.c_float, [C.c_float, C.c_float])
+_sig("qldpc_parity_bits_to_punct", C.c_int, [C.c_int, C.c_int, C.c_float])
+_sig("qldpc_code_from_alist", C.c_int, [C.c_char_p, C.POINTER(_vp)])
+_sig("qldpc_code_from_qc", C.c_int, [C.c_char_p, C.POINTER(_vp)])
+_sig("qldpc_code_from_edges", C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(_vp)])
+_sig("qldpc_code_ira", C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint64, C.POINTER(_vp)])
+_sig("qldpc_code_free", None, [_vp])
+for _n in ("n", "m", "e", "max_cn_degree", "max_vn_degree", "is_ira", "layer_count"):
+    _sig("qldpc_code_" + _n, C.c_int, [_vp])
+_sig("qldpc_code_export_edges", C.c_int, [_vp, _ip, _ip])
+_sig("qldpc_code_layer_order", C.c_int, [_vp, _ip, _ip])
+_sig("qldpc_code_syndrome_host", C.c_int, [_vp, _ip, _ip])
+_sig("qldpc_decoder_cfg_default", None, [C.POINTER(DecoderCfg)])
+_sig("qldpc_decoder_create", C.c_int, [_vp, C.c_int, _ip, C.POINTER(DecoderCfg), C.POINTER(_vp)])
+_sig("qldpc_decoder_free", None, [_vp])
+_sig("qldpc_decoder_set_stream", C.c_int, [_vp, _vp])
+_sig("qldpc_decoder_reset", C.c_int, [_vp])
+_sig("qldpc_decoder_device_bytes", C.c_size_t, [_vp])
+_sig("qldpc_decode_siho", C.c_int, [_vp, _fp, _ip, C.c_int])
+_sig("qldpc_load_llr_dev", C.c_int, [_vp, _vp, C.c_int])
+_sig("qldpc_load_bits_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_int])
+_sig("qldpc_run", C.c_int, [_vp])
+_sig("qldpc_fetch_packed_dev", C.c_int, [_vp, _vp])
+_sig("qldpc_fetch_info_dev", C.c_int, [_vp, _vp])
+_sig("qldpc_fetch_status_dev", C.c_int, [_vp, _vp, _vp])
+_sig("qldpc_fetch_post_dev", C.c_int, [_vp, _vp])
+_sig("qldpc_sync", C.c_int, [_vp])
+_sig("qldpc_profile_enable", C.c_int, [_vp, C.c_int])
+_sig("qldpc_profile_read", C.c_int, [_vp, C.POINTER(KernelStat), C.c_int])
+_sig("qldpc_profile_clear", C.c_int, [_vp])
+_sig("qldpc_last_run_iterations", C.c_int, [_vp])
+_sig("qldpc_encoder_create", C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(_vp)])
+_sig("qldpc_encoder_free", None, [_vp])
+_sig("qldpc_encoder_k", C.c_int, [_vp])
+_sig("qldpc_encoder_info_bits_pos", C.c_int, [_vp, _ip])
+_sig("qldpc_encode", C.c_int, [_vp, _ip, _ip, C.c_int])
+_sig("qldpc_encode_packed_dev", C.c_int, [_vp, _vp, _vp, C.c_int, _vp])
+
+
+class QldpcError(RuntimeError):
+    """Raised where the AFF3CT objects would throw tools::exception; carries the C status."""
+
+    def __init__(self, status, where):
+        self.status = status
+        msg = _L.qldpc_last_error().decode(errors="replace")
+        super().__init__("%s: %s (%d)%s" % (where, _L.qldpc_strerror(status).decode(), status, (": " + msg) if msg else ""))
+
+
+def _chk(rc, where):
+    if rc < 0:
+        raise QldpcError(rc, where)
+    return rc
+
+
+def version():
+    return _L.qldpc_version()
+
+
+def device_count():
+    return _L.qldpc_device_count()
+
+
+def llr_from_ber(p):
+    """LLR(BER) macro, BS/src/main.cpp:20."""
+    return _L.qldpc_llr_from_ber(float(p))
+
+
+def bsc_llr(p):
+    """|LLR| Modem_OOK_BSC gives a channel bit, BS/src/main.cpp:317,348."""
+    return _L.qldpc_bsc_llr(float(p))
+
+
+def binary_entropy(q):
+    return _L.qldpc_binary_entropy(float(q))
+
+
+def min_code_rate(qber, efficiency):
+    return _L.qldpc_min_code_rate(float(qber), float(efficiency))
+
+
+def parity_bits_to_punct(N, K, target_cr):
+    return _L.qldpc_parity_bits_to_punct(int(N), int(K), float(target_cr))
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Code:
+    """Parity-check matrix H (tools::Sparse_matrix as the harness holds it; rows = variable nodes)."""
+
+    def __init__(self, handle):
+        self._h = _vp(handle)
+        self.N = _L.qldpc_code_n(self._h)
+        self.M = _L.qldpc_code_m(self._h)
+        self.E = _L.qldpc_code_e(self._h)
+        self.max_cn_degree = _L.qldpc_code_max_cn_degree(self._h)
+        self.max_vn_degree = _L.qldpc_code_max_vn_degree(self._h)
+        self.is_ira = bool(_L.qldpc_code_is_ira(self._h))
+        self.n_layers = _L.qldpc_code_layer_count(self._h)
+
+    @classmethod
+    def from_alist(cls, path):
+        h = _vp()
+        _chk(_L.qldpc_code_from_alist(os.fsencode(path), C.byref(h)), "Code.from_alist")
+        return cls(h.value)
+
+    @classmethod
+    def from_qc(cls, path):
+        h = _vp()
+        _chk(_L.qldpc_code_from_qc(os.fsencode(path), C.byref(h)), "Code.from_qc")
+        return cls(h.value)
+
+    @classmethod
+    def from_edges(cls, N, M, var, chk):
+        var, chk = _np_i32(var), _np_i32(chk)
+        if var.shape != chk.shape:
+            raise QldpcError(-6, "Code.from_edges")
+        h = _vp()
+        _chk(_L.qldpc_code_from_edges(int(N), int(M), int(var.size), var.ctypes.data_as(_ip), chk.ctypes.data_as(_ip),
+                                      C.byref(h)), "Code.from_edges")
+        return cls(h.value)
+
+    @classmethod
+    def ira(cls, N, K, hi_frac=0.125, dv_hi=11, dv_lo=3, seed=7):
+        h = _vp()
+        _chk(_L.qldpc_code_ira(int(N), int(K), float(hi_frac), int(dv_hi), int(dv_lo), int(seed), C.byref(h)), "Code.ira")
+        return cls(h.value)
+
+    def edges(self):
+        var = np.empty(self.E, np.int32)
+        chk = np.empty(self.E, np.int32)
+        _chk(_L.qldpc_code_export_edges(self._h, var.ctypes.data_as(_ip), chk.ctypes.data_as(_ip)), "Code.edges")
+        return var, chk
+
+    def layer_order(self):
+        """(check_order[M], layer_ptr[n_layers+1], natural) of the horizontal-layered sweep."""
+        order = np.empty(self.M, np.int32)
+        ptr = np.empty(self.n_layers + 1, np.int32)
+        nat = _chk(_L.qldpc_code_layer_order(self._h, order.ctypes.data_as(_ip), ptr.ctypes.data_as(_ip)), "Code.layer_order")
+        return order, ptr, bool(nat)
+
+    def syndrome(self, x):
+        x = _np_i32(x)
+        s = np.empty(self.M, np.int32)
+        w = _chk(_L.qldpc_code_syndrome_host(self._h, x.ctypes.data_as(_ip), s.ctypes.data_as(_ip)), "Code.syndrome")
+        return w, s
+
+    def __del__(self):
+        try:
+            _L.qldpc_code_free(self._h)
+        except Exception:
+            pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Decoder:
+    """module::Decoder_LDPC_BP_{flooding,horizontal_layered}<B,Q,Rule> as a batched HIP decoder.
+
+    Decoder(code, K, n_ite, info_bits_pos, rule=("NMS", 0.75), enable_syndrome, syndrome_depth, n_frames)
+    mirrors the AFF3CT ctor (VAR/main.cpp (alist-v1.0.1):203-237).
+    """
+
+    def __init__(self, code, K, n_ite, info_bits_pos=None, rule="SPA", rule_param=0.0, enable_syndrome=True,
+                 syndrome_depth=1, n_frames=1, schedule="flooding", device=0, frames_per_lane=0):
+        cfg = DecoderCfg()
+        _L.qldpc_decoder_cfg_default(C.byref(cfg))
+        cfg.schedule = SCHEDULES[schedule]
+        cfg.rule = RULES[rule]
+        cfg.rule_param = float(rule_param)
+        cfg.n_ite = int(n_ite)
+        cfg.enable_syndrome = int(bool(enable_syndrome))
+        cfg.syndrome_depth = int(syndrome_depth)
+        cfg.max_frames = int(n_frames)
+        cfg.device = int(device)
+        cfg.frames_per_lane = int(frames_per_lane)
+        pos = None
+        if info_bits_pos is not None:
+            pos = _np_i32(info_bits_pos)
+            if pos.size != K:
+                raise QldpcError(-6, "Decoder: len(info_bits_pos) != K")
+        h = _vp()
+        _chk(_L.qldpc_decoder_create(code._h, int(K), pos.ctypes.data_as(_ip) if pos is not None else None,
+                                     C.byref(cfg), C.byref(h)), "Decoder")
+        self._h = h
+        self.code, self.K, self.N = code, int(K), code.N
+        self.max_frames, self.device = int(n_frames), int(device)
+        self.n_frames = 0
+
+    # -- AFF3CT mirror (host vectors) --------------------------------------------------------
+    def decode_siho(self, Y_N):
+        """decode_siho(LLRs, dec_bits): Y_N[n_frames, N] float32 -> V_K[n_frames, K] int32 (numpy)."""
+        Y = np.ascontiguousarray(Y_N, dtype=np.float32)
+        if Y.ndim == 1:
+            Y = Y[None, :]
+        if Y.shape[1] != self.N:
+            raise QldpcError(-6, "decode_siho: Y_N has %d columns, N = %d" % (Y.shape[1], self.N))
+        V = np.empty((Y.shape[0], self.K), np.int32)
+        _chk(_L.qldpc_decode_siho(self._h, Y.ctypes.data_as(_fp), V.ctypes.data_as(_ip), Y.shape[0]), "decode_siho")
+        self.n_frames = Y.shape[0]
+        return V
+
+    def reset(self):
+        _chk(_L.qldpc_decoder_reset(self._h), "reset")
+
+    # -- staged HBM-resident path (torch tensors own the buffers) ----------------------------
+    def set_stream(self, stream=None):
+        torch = _torch()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _chk(_L.qldpc_decoder_set_stream(self._h, _vp(s.cuda_stream)), "set_stream")
+
+    def load_llr(self, llr):
+        torch = _torch()
+        assert llr.is_cuda and llr.dtype == torch.float32 and llr.is_contiguous() and llr.dim() == 2 and llr.shape[1] == self.N
+        self.n_frames = llr.shape[0]
+        _chk(_L.qldpc_load_llr_dev(self._h, _vp(llr.data_ptr()), llr.shape[0]), "load_llr")
+
+    def load_bits(self, bits, llr_mag, vn_class=None):
+        torch = _torch()
+        W = (self.N + 31) // 32
+        assert bits.is_cuda and bits.dtype in (torch.int32, torch.uint32) and bits.is_contiguous() and bits.shape[1] == W
+        assert llr_mag.is_cuda and llr_mag.dtype == torch.float32 and llr_mag.numel() == bits.shape[0]
+        if vn_class is not None:
+            assert vn_class.is_cuda and vn_class.dtype == torch.uint8 and vn_class.numel() == self.N
+        self.n_frames = bits.shape[0]
+        _chk(_L.qldpc_load_bits_dev(self._h, _vp(bits.data_ptr()), _vp(llr_mag.data_ptr()),
+                                    _vp(vn_class.data_ptr()) if vn_class is not None else None, bits.shape[0]), "load_bits")
+
+    def run(self):
+        _chk(_L.qldpc_run(self._h), "run")
+
+    def fetch_packed(self, out=None):
+        torch = _torch()
+        W = (self.N + 31) // 32
+        if out is None:
+            out = torch.empty((self.n_frames, W), dtype=torch.int32, device="cuda:%d" % self.device)
+        _chk(_L.qldpc_fetch_packed_dev(self._h, _vp(out.data_ptr())), "fetch_packed")
+        return out
+
+    def fetch_info(self, out=None):
+        torch = _torch()
+        if out is None:
+            out = torch.empty((self.n_frames, self.K), dtype=torch.int32, device="cuda:%d" % self.device)
+        _chk(_L.qldpc_fetch_info_dev(self._h, _vp(out.data_ptr())), "fetch_info")
+        return out
+
+    def fetch_status(self):
+        torch = _torch()
+        it = torch.empty(self.n_frames, dtype=torch.int32, device="cuda:%d" % self.device)
+        ok = torch.empty(self.n_frames, dtype=torch.int32, device="cuda:%d" % self.device)
+        _chk(_L.qldpc_fetch_status_dev(self._h, _vp(it.data_ptr()), _vp(ok.data_ptr())), "fetch_status")
+        return it, ok
+
+    def fetch_post(self):
+        torch = _torch()
+        out = torch.empty((self.n_frames, self.N), dtype=torch.float32, device="cuda:%d" % self.device)
+        _chk(_L.qldpc_fetch_post_dev(self._h, _vp(out.data_ptr())), "fetch_post")
+        return out
+
+    def sync(self):
+        _chk(_L.qldpc_sync(self._h), "sync")
+
+    @property
+    def device_bytes(self):
+        return _L.qldpc_decoder_device_bytes(self._h)
+
+    @property
+    def last_run_iterations(self):
+        return _L.qldpc_last_run_iterations(self._h)
+
+    # -- measurement ---------------------------------------------------------------------------
+    def profile(self, on=True):
+        _chk(_L.qldpc_profile_enable(self._h, int(on)), "profile")
+
+    def profile_clear(self):
+        _chk(_L.qldpc_profile_clear(self._h), "profile_clear")
+
+    def profile_read(self):
+        arr = (KernelStat * 16)()
+        n = _chk(_L.qldpc_profile_read(self._h, arr, 16), "profile_read")
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                     alg_bytes=float(arr[i].alg_bytes)) for i in range(n)]
+
+    def __del__(self):
+        try:
+            _L.qldpc_decoder_free(self._h)
+        except Exception:
+            pass
+
+
+class Encoder:
+    """m.encoder->encode (BS/src/main.cpp:341): method 'IRA' or 'IDENTITY' (Encoder_LDPC_from_H)."""
+
+    def __init__(self, code, method="IDENTITY", device=0):
+        h = _vp()
+        _chk(_L.qldpc_encoder_create(code._h, method.encode(), int(device), C.byref(h)), "Encoder")
+        self._h = h
+        self.code, self.N, self.device = code, code.N, int(device)
+        self.K = _L.qldpc_encoder_k(self._h)
+        pos = np.empty(self.K, np.int32)
+        _chk(_L.qldpc_encoder_info_bits_pos(self._h, pos.ctypes.data_as(_ip)), "Encoder.info_bits_pos")
+        self.info_bits_pos = pos
+
+    def encode(self, U_K):
+        U = _np_i32(U_K)
+        if U.ndim == 1:
+            U = U[None, :]
+        if U.shape[1] != self.K:
+            raise QldpcError(-6, "encode: U_K has %d columns, K = %d" % (U.shape[1], self.K))
+        X = np.empty((U.shape[0], self.N), np.int32)
+        _chk(_L.qldpc_encode(self._h, U.ctypes.data_as(_ip), X.ctypes.data_as(_ip), U.shape[0]), "encode")
+        return X
+
+    def encode_packed(self, info, stream=None):
+        torch = _torch()
+        Wk, Wn = (self.K + 31) // 32, (self.N + 31) // 32
+        assert info.is_cuda and info.dtype == torch.int32 and info.is_contiguous() and info.shape[1] == Wk
+        out = torch.empty((info.shape[0], Wn), dtype=torch.int32, device=info.device)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        _chk(_L.qldpc_encode_packed_dev(self._h, _vp(info.data_ptr()), _vp(out.data_ptr()), info.shape[0], _vp(s.cuda_stream)),
+             "encode_packed")
+        return out
+
+    def __del__(self):
+        try:
+            _L.qldpc_encoder_free(self._h)
+        except Exception:
+            pass
+
+
+# ---- packed-bit helpers (ProcessBlock.mainBufPtr layout, helpers.h:65-70) ----------------------
+
+def pack_bits(bits):
+    """bits[..., n] of 0/1 -> uint32 words [..., ceil(n/32)], bit i <-> word[i/32] & (1 << (31 - i%32))."""
+    b = np.asarray(bits).astype(np.uint8)
+    n = b.shape[-1]
+    pad = (-n) % 32
+    if pad:
+        b = np.concatenate([b, np.zeros(b.shape[:-1] + (pad,), np.uint8)], axis=-1)
+    by = np.packbits(b, axis=-1, bitorder="big")
+    return by.reshape(b.shape[:-1] + (-1, 4)).astype(np.uint32) @ np.array([1 << 24, 1 << 16, 1 << 8, 1], np.uint32)
+
+
+def unpack_bits(words, n):
+    w = np.asarray(words).astype(np.uint32)
+    by = np.stack([(w >> 24) & 255, (w >> 16) & 255, (w >> 8) & 255, w & 255], axis=-1).astype(np.uint8)
+    bits = np.unpackbits(by.reshape(w.shape[:-1] + (-1,)), axis=-1, bitorder="big")
+    return bits[..., :n]

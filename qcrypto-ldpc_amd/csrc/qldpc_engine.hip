@@ -1,0 +1,717 @@
+/*
+ * qldpc_engine.hip -- decoder object, launch sequencing and the C ABI of the batched BP decoder.
+ *
+ * Mirrors module::Decoder_LDPC_BP_flooding / _horizontal_layered as the reference harness drives
+ * them (BS/src/main.cpp:193,365,389; VAR/main.cpp (alist-v1.0.1):179-256,438): create(K, N, n_ite,
+ * H, info_bits_pos, rule, enable_syndrome, syndrome_depth, n_frames), decode_siho(Y_N, V_K), reset().
+ * Everything heavy is a HIP kernel from qldpc_kernels.h; there is no CPU fallback.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/qldpc.h"
+#include "qldpc_graph.h"
+#include "qldpc_kernels.h"
+
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            qldpc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));     \
+            return QLDPC_EHIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+extern "C" int qldpc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ------------------------------------------------------------------ decoder object ----------- */
+
+enum { KS_CN = 0, KS_VN, KS_LAYER, KS_SYND, KS_STATUS, KS_LOAD, KS_FETCH, KS_COUNT };
+static const char *const ks_names[KS_COUNT] = {"cn_update", "vn_update", "layer_update", "syndrome", "status", "load", "fetch"};
+
+struct prof_rec { int kind; double bytes; hipEvent_t a, b; };
+
+struct bucket { int cap; int n; int *d_list; };   /* cap = register-resident degree bound, 0 = any degree */
+
+struct qldpc_decoder {
+    qldpc_decoder_cfg cfg;
+    int N, M, E, K;
+    int V, FG, G;
+    int device;
+    hipStream_t stream;
+    /* graph on device */
+    int *d_cn_ptr, *d_cn_tr, *d_cn_var, *d_vn_ptr, *d_info_pos;
+    std::vector<bucket> cn_buckets, vn_buckets;
+    std::vector<std::vector<bucket>> layer_buckets;   /* per layer */
+    int n_layers;
+    /* state */
+    float *d_llr, *d_a, *d_b;        /* flooding: a = v2c, b = c2v ; layered: a = post, b = msg */
+    float *d_post;                   /* lazily allocated by fetch_post */
+    u64 *d_sgn, *d_hard, *d_unsat, *d_done;
+    int *d_depth, *d_iters, *d_active;
+    int *h_active;                   /* pinned */
+    size_t bytes;
+    int n_frames;                    /* loaded */
+    int loaded, ran;
+    int last_iters;
+    int poll_every;
+    /* profiling */
+    int prof_on;
+    std::vector<prof_rec> prof_pending;
+    qldpc_kernel_stat stats[KS_COUNT];
+};
+
+static const int CN_CAPS[] = {8, 12, 20, 40};
+static const int VN_CAPS[] = {4, 12};
+
+template <typename T> static int dev_alloc(qldpc_decoder *d, T **p, size_t n)
+{
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) { qldpc_set_error("hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e)); return QLDPC_ENOMEM; }
+    d->bytes += n * sizeof(T);
+    return QLDPC_OK;
+}
+
+static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_ids, const int *caps, int n_caps, std::vector<bucket> &out)
+{
+    std::vector<std::vector<int>> lists(n_caps + 1);
+    for (int i = 0; i < n_ids; i++) {
+        const int id = ids ? ids[i] : i;
+        const int deg = ptr[id + 1] - ptr[id];
+        int b = n_caps;
+        for (int k = 0; k < n_caps; k++) if (deg <= caps[k]) { b = k; break; }
+        lists[b].push_back(id);
+    }
+    for (int k = 0; k <= n_caps; k++) {
+        if (lists[k].empty()) continue;
+        bucket bk;
+        bk.cap = k < n_caps ? caps[k] : 0;
+        bk.n = (int)lists[k].size();
+        int rc = dev_alloc(d, &bk.d_list, lists[k].size());
+        if (rc != QLDPC_OK) return rc;
+        HIPCHK(hipMemcpy(bk.d_list, lists[k].data(), lists[k].size() * sizeof(int), hipMemcpyHostToDevice));
+        out.push_back(bk);
+    }
+    return QLDPC_OK;
+}
+
+extern "C" void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->schedule = QLDPC_SCHED_FLOODING;
+    cfg->rule = QLDPC_RULE_SPA;        /* the harness default, BS/src/main.cpp:193 */
+    cfg->rule_param = 0.0f;
+    cfg->n_ite = 100;                  /* BS/src/main.cpp:95-104 */
+    cfg->enable_syndrome = 1;
+    cfg->syndrome_depth = 1;
+    cfg->max_frames = 1;
+    cfg->device = 0;
+    cfg->frames_per_lane = 0;
+}
+
+extern "C" void qldpc_decoder_free(qldpc_decoder *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream); else (void)hipDeviceSynchronize();
+    for (auto &r : d->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto &b : d->cn_buckets) (void)hipFree(b.d_list);
+    for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
+    for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
+    (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
+    (void)hipFree(d->d_llr); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
+    (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
+    (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active);
+    if (d->h_active) (void)hipHostFree(d->h_active);
+    delete d;
+}
+
+static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, const qldpc_decoder_cfg *cfg, qldpc_decoder *d)
+{
+    d->cfg = *cfg;
+    d->N = code->N; d->M = code->M; d->E = code->E; d->K = K;
+    d->device = cfg->device;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { qldpc_set_error("no HIP device visible: libqldpc has no CPU fallback"); return QLDPC_ENODEV; }
+    if (cfg->device < 0 || cfg->device >= ndev) { qldpc_set_error("device %d out of range (%d visible)", cfg->device, ndev); return QLDPC_ENODEV; }
+    HIPCHK(hipSetDevice(cfg->device));
+    int V = cfg->frames_per_lane;
+    if (V == 0) V = cfg->max_frames >= 2048 ? 4 : (cfg->max_frames >= 512 ? 2 : 1);
+    if (const char *e = getenv("QLDPC_FRAMES_PER_LANE")) { int x = atoi(e); if (x == 1 || x == 2 || x == 4) V = x; }
+    d->V = V; d->FG = 64 * V; d->G = (cfg->max_frames + d->FG - 1) / d->FG;
+    d->poll_every = d->G >= 8 ? 2 : 0;
+    if (const char *e = getenv("QLDPC_POLL_EVERY")) d->poll_every = atoi(e);
+
+    int rc;
+    if ((rc = dev_alloc(d, &d->d_cn_ptr, (size_t)d->M + 1))) return rc;
+    if ((rc = dev_alloc(d, &d->d_cn_tr, (size_t)d->E))) return rc;
+    if ((rc = dev_alloc(d, &d->d_cn_var, (size_t)d->E))) return rc;
+    if ((rc = dev_alloc(d, &d->d_vn_ptr, (size_t)d->N + 1))) return rc;
+    if ((rc = dev_alloc(d, &d->d_info_pos, (size_t)K))) return rc;
+    HIPCHK(hipMemcpy(d->d_cn_ptr, code->cn_ptr, sizeof(int) * ((size_t)d->M + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->d_cn_tr, code->transpose, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->d_cn_var, code->cn_var, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->d_vn_ptr, code->vn_ptr, sizeof(int) * ((size_t)d->N + 1), hipMemcpyHostToDevice));
+    {
+        std::vector<int> pos((size_t)K);
+        for (int i = 0; i < K; i++) {
+            pos[i] = info_bits_pos ? info_bits_pos[i] : i;
+            if (pos[i] < 0 || pos[i] >= d->N) { qldpc_set_error("info_bits_pos[%d] = %d out of range", i, pos[i]); return QLDPC_EINVAL; }
+        }
+        HIPCHK(hipMemcpy(d->d_info_pos, pos.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice));
+    }
+    if (cfg->schedule == QLDPC_SCHED_FLOODING) {
+        if ((rc = make_buckets(d, code->cn_ptr, nullptr, d->M, CN_CAPS, 4, d->cn_buckets))) return rc;
+        if ((rc = make_buckets(d, code->vn_ptr, nullptr, d->N, VN_CAPS, 2, d->vn_buckets))) return rc;
+    } else {
+        d->n_layers = code->n_layers;
+        d->layer_buckets.resize((size_t)code->n_layers);
+        for (int l = 0; l < code->n_layers; l++)
+            if ((rc = make_buckets(d, code->cn_ptr, code->layer_order + code->layer_ptr[l], code->layer_ptr[l + 1] - code->layer_ptr[l], CN_CAPS, 4, d->layer_buckets[(size_t)l]))) return rc;
+    }
+    const size_t G = (size_t)d->G, FG = (size_t)d->FG;
+    if ((rc = dev_alloc(d, &d->d_llr, G * d->N * FG))) return rc;
+    if (cfg->schedule == QLDPC_SCHED_FLOODING) {
+        if ((rc = dev_alloc(d, &d->d_a, G * d->E * FG))) return rc;
+        if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
+    } else {
+        if ((rc = dev_alloc(d, &d->d_a, G * d->N * FG))) return rc;
+        if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
+    }
+    if ((rc = dev_alloc(d, &d->d_sgn, G * d->N * V))) return rc;
+    if ((rc = dev_alloc(d, &d->d_hard, G * d->N * V))) return rc;
+    if ((rc = dev_alloc(d, &d->d_unsat, G * V))) return rc;
+    if ((rc = dev_alloc(d, &d->d_done, G * V))) return rc;
+    if ((rc = dev_alloc(d, &d->d_depth, G * FG))) return rc;
+    if ((rc = dev_alloc(d, &d->d_iters, G * FG))) return rc;
+    if ((rc = dev_alloc(d, &d->d_active, 1))) return rc;
+    HIPCHK(hipHostMalloc((void **)&d->h_active, sizeof(int)));
+    for (int k = 0; k < KS_COUNT; k++) { memset(&d->stats[k], 0, sizeof(d->stats[k])); snprintf(d->stats[k].name, sizeof(d->stats[k].name), "%s", ks_names[k]); }
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *info_bits_pos, const qldpc_decoder_cfg *cfg, qldpc_decoder **out)
+{
+    if (!out) return QLDPC_EINVAL;
+    *out = nullptr;
+    if (!code || !cfg) { qldpc_set_error("decoder_create: null code/cfg"); return QLDPC_EINVAL; }
+    /* AFF3CT's ctor throws on these (Decoder_LDPC_BP: 'N' vs H.get_n_rows(), K <= N, n_ite > 0) */
+    if (K <= 0 || K > code->N) { qldpc_set_error("decoder_create: K=%d not in (0, N=%d]", K, code->N); return QLDPC_ESIZE; }
+    if (cfg->n_ite <= 0) { qldpc_set_error("decoder_create: n_ite=%d", cfg->n_ite); return QLDPC_EINVAL; }
+    if (cfg->max_frames <= 0) { qldpc_set_error("decoder_create: max_frames=%d", cfg->max_frames); return QLDPC_EINVAL; }
+    if (cfg->rule < QLDPC_RULE_MS || cfg->rule > QLDPC_RULE_AMS_MINSTAR) { qldpc_set_error("decoder_create: rule=%d", cfg->rule); return QLDPC_EINVAL; }
+    if (cfg->schedule != QLDPC_SCHED_FLOODING && cfg->schedule != QLDPC_SCHED_HLAYERED) { qldpc_set_error("decoder_create: schedule=%d", cfg->schedule); return QLDPC_EINVAL; }
+    if (cfg->enable_syndrome && cfg->syndrome_depth < 1) { qldpc_set_error("decoder_create: syndrome_depth=%d", cfg->syndrome_depth); return QLDPC_EINVAL; }
+    if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 && cfg->frames_per_lane != 4) { qldpc_set_error("decoder_create: frames_per_lane=%d", cfg->frames_per_lane); return QLDPC_EINVAL; }
+    qldpc_decoder *d = new (std::nothrow) qldpc_decoder();
+    if (!d) return QLDPC_ENOMEM;
+    int rc = create_impl(code, K, info_bits_pos, cfg, d);
+    if (rc != QLDPC_OK) { qldpc_decoder_free(d); return rc; }
+    *out = d;
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_decoder_set_stream(qldpc_decoder *d, void *s) { if (!d) return QLDPC_EINVAL; d->stream = (hipStream_t)s; return QLDPC_OK; }
+extern "C" size_t qldpc_decoder_device_bytes(const qldpc_decoder *d) { return d ? d->bytes : 0; }
+extern "C" int qldpc_last_run_iterations(const qldpc_decoder *d) { return d ? d->last_iters : QLDPC_EINVAL; }
+
+/* reset(): the next decode starts from chk_to_var = 0 (BS/src/main.cpp:389).  Every qldpc_run starts
+ * from that state anyway (frames are independent decodes), so this only drops loaded frames. */
+extern "C" int qldpc_decoder_reset(qldpc_decoder *d)
+{
+    if (!d) return QLDPC_EINVAL;
+    d->loaded = 0; d->ran = 0; d->n_frames = 0;
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_sync(qldpc_decoder *d)
+{
+    if (!d) return QLDPC_EINVAL;
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return QLDPC_OK;
+}
+
+/* ------------------------------------------------------------------ profiling ---------------- */
+
+struct prof_scope {
+    qldpc_decoder *d; int kind; double bytes; hipEvent_t a, b; bool on;
+    prof_scope(qldpc_decoder *d_, int kind_, double bytes_) : d(d_), kind(kind_), bytes(bytes_), a(nullptr), b(nullptr), on(d_->prof_on != 0)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->stream); }
+    }
+    ~prof_scope()
+    {
+        if (on) { (void)hipEventRecord(b, d->stream); d->prof_pending.push_back({kind, bytes, a, b}); }
+    }
+};
+
+extern "C" int qldpc_profile_enable(qldpc_decoder *d, int on) { if (!d) return QLDPC_EINVAL; d->prof_on = on; return QLDPC_OK; }
+
+static int prof_fold(qldpc_decoder *d)
+{
+    if (d->prof_pending.empty()) return QLDPC_OK;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    for (auto &r : d->prof_pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            d->stats[r.kind].launches++;
+            d->stats[r.kind].total_ms += ms;
+            d->stats[r.kind].alg_bytes += r.bytes;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    d->prof_pending.clear();
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_profile_read(qldpc_decoder *d, qldpc_kernel_stat *out, int cap)
+{
+    if (!d || (!out && cap > 0)) return QLDPC_EINVAL;
+    HIPCHK(hipSetDevice(d->device));
+    int rc = prof_fold(d);
+    if (rc) return rc;
+    int n = 0;
+    for (int k = 0; k < KS_COUNT && n < cap; k++) if (d->stats[k].launches) out[n++] = d->stats[k];
+    return n;
+}
+
+extern "C" int qldpc_profile_clear(qldpc_decoder *d)
+{
+    if (!d) return QLDPC_EINVAL;
+    int rc = prof_fold(d);
+    if (rc) return rc;
+    for (int k = 0; k < KS_COUNT; k++) { d->stats[k].launches = 0; d->stats[k].total_ms = 0; d->stats[k].alg_bytes = 0; }
+    return QLDPC_OK;
+}
+
+/* ------------------------------------------------------------------ launch helpers ----------- */
+
+#define LAUNCHCHK()                                                                                     \
+    do {                                                                                                \
+        hipError_t e__ = hipGetLastError();                                                             \
+        if (e__ != hipSuccess) { qldpc_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); return QLDPC_EHIP; } \
+    } while (0)
+
+static inline int grid_x(const qldpc_decoder *d, int n_items)
+{
+    const int per_block = QK_WAVES;
+    int want = (n_items + per_block - 1) / per_block;
+    int cap = 8192 / std::max(1, d->G);
+    if (cap < 1) cap = 1;
+    return std::max(1, std::min(want, cap));
+}
+
+static int family_of(int rule)
+{
+    switch (rule) {
+    case QLDPC_RULE_MS: case QLDPC_RULE_OMS: case QLDPC_RULE_NMS: return QK_FAM_MS;
+    case QLDPC_RULE_SPA: return QK_FAM_SPA;
+    case QLDPC_RULE_LSPA: return QK_FAM_LSPA;
+    default: return QK_FAM_AMS;
+    }
+}
+
+template <int V, int CAP, int FAM>
+static void launch_cn_one(qldpc_decoder *d, const bucket &b)
+{
+    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
+    qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_tr,
+                       (size_t)d->E * d->FG, d->d_done, r);
+}
+template <int V, int FAM>
+static void launch_cn_fam(qldpc_decoder *d, const bucket &b)
+{
+    switch (b.cap) {
+    case 8: launch_cn_one<V, 8, FAM>(d, b); break;
+    case 12: launch_cn_one<V, 12, FAM>(d, b); break;
+    case 20: launch_cn_one<V, 20, FAM>(d, b); break;
+    case 40: launch_cn_one<V, 40, FAM>(d, b); break;
+    default: launch_cn_one<V, 0, FAM>(d, b); break;
+    }
+}
+template <int V>
+static void launch_cn(qldpc_decoder *d, const bucket &b)
+{
+    switch (family_of(d->cfg.rule)) {
+    case QK_FAM_MS: launch_cn_fam<V, QK_FAM_MS>(d, b); break;
+    case QK_FAM_SPA: launch_cn_fam<V, QK_FAM_SPA>(d, b); break;
+    case QK_FAM_LSPA: launch_cn_fam<V, QK_FAM_LSPA>(d, b); break;
+    default: launch_cn_fam<V, QK_FAM_AMS>(d, b); break;
+    }
+}
+
+template <int V, int CAP, int FAM>
+static void launch_layer_one(qldpc_decoder *d, const bucket &b)
+{
+    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
+    qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
+                       d->N, (size_t)d->E * d->FG, d->d_done, r);
+}
+template <int V, int FAM>
+static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
+{
+    switch (b.cap) {
+    case 8: launch_layer_one<V, 8, FAM>(d, b); break;
+    case 12: launch_layer_one<V, 12, FAM>(d, b); break;
+    case 20: launch_layer_one<V, 20, FAM>(d, b); break;
+    case 40: launch_layer_one<V, 40, FAM>(d, b); break;
+    default: launch_layer_one<V, 0, FAM>(d, b); break;
+    }
+}
+template <int V>
+static void launch_layer(qldpc_decoder *d, const bucket &b)
+{
+    switch (family_of(d->cfg.rule)) {
+    case QK_FAM_MS: launch_layer_fam<V, QK_FAM_MS>(d, b); break;
+    case QK_FAM_SPA: launch_layer_fam<V, QK_FAM_SPA>(d, b); break;
+    case QK_FAM_LSPA: launch_layer_fam<V, QK_FAM_LSPA>(d, b); break;
+    default: launch_layer_fam<V, QK_FAM_AMS>(d, b); break;
+    }
+}
+
+template <int V, int CAP, int MODE>
+static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
+{
+    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
+    hipLaunchKernelGGL((qk_vn_flood<V, CAP, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
+                       b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
+}
+template <int V, int MODE>
+static void launch_vn(qldpc_decoder *d, const bucket &b, float *post_out)
+{
+    if (MODE == QK_VN_FIRST) { launch_vn_one<V, 0, MODE>(d, b, post_out); return; }
+    switch (b.cap) {
+    case 4: launch_vn_one<V, 4, MODE>(d, b, post_out); break;
+    case 12: launch_vn_one<V, 12, MODE>(d, b, post_out); break;
+    default: launch_vn_one<V, 0, MODE>(d, b, post_out); break;
+    }
+}
+
+/* algorithmic bytes: only live (non-padding) frames are counted */
+static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * 4.0 * d->n_frames; }
+static double bytes_vn(const qldpc_decoder *d, int mode)
+{
+    if (mode == QK_VN_FIRST) return ((double)d->E + d->N) * 4.0 * d->n_frames;
+    if (mode == QK_VN_POST) return ((double)d->E + d->N) * 4.0 * d->n_frames;
+    return (2.0 * d->E + d->N) * 4.0 * d->n_frames;
+}
+static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * 4.0 * d->n_frames; }
+
+template <int V, int MODE>
+static int vn_pass(qldpc_decoder *d, float *post_out)
+{
+    prof_scope ps(d, KS_VN, bytes_vn(d, MODE));
+    for (auto &b : d->vn_buckets) { launch_vn<V, MODE>(d, b, post_out); LAUNCHCHK(); }
+    return QLDPC_OK;
+}
+template <int V>
+static int cn_pass(qldpc_decoder *d)
+{
+    prof_scope ps(d, KS_CN, bytes_cn(d));
+    for (auto &b : d->cn_buckets) { launch_cn<V>(d, b); LAUNCHCHK(); }
+    return QLDPC_OK;
+}
+template <int V>
+static int synd_pass(qldpc_decoder *d, const u64 *mask, int skip_done)
+{
+    prof_scope ps(d, KS_SYND, (double)d->E * 8.0 * d->G * V);
+    int bx = std::max(1, std::min((d->M + 255) / 256, 4096 / std::max(1, d->G)));
+    hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(256), 0, d->stream, mask, d->d_cn_ptr, d->d_cn_var, d->M, d->N,
+                       d->d_unsat, d->d_done, skip_done);
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+template <int V>
+static int status_pass(qldpc_decoder *d, int ite_done)
+{
+    prof_scope ps(d, KS_STATUS, 0.0);
+    HIPCHK(hipMemsetAsync(d->d_active, 0, sizeof(int), d->stream));
+    hipLaunchKernelGGL((qk_status<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->G,
+                       d->cfg.syndrome_depth, ite_done, d->d_active);
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+/* blocking: how many groups still have unconverged frames */
+static int poll_active(qldpc_decoder *d, int *active)
+{
+    HIPCHK(hipMemcpyAsync(d->h_active, d->d_active, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *active = *d->h_active;
+    return QLDPC_OK;
+}
+
+/* ------------------------------------------------------------------ run ---------------------- */
+
+template <int V>
+static int run_flooding(qldpc_decoder *d)
+{
+    int rc;
+    const int n_ite = d->cfg.n_ite;
+    if ((rc = vn_pass<V, QK_VN_FIRST>(d, nullptr))) return rc;
+    int ite = 0;
+    for (; ite < n_ite; ite++) {
+        if ((rc = cn_pass<V>(d))) return rc;
+        if (ite == n_ite - 1) { ite++; break; }
+        if ((rc = vn_pass<V, QK_VN_NORMAL>(d, nullptr))) return rc;
+        if (d->cfg.enable_syndrome) {
+            if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
+            if ((rc = status_pass<V>(d, ite + 1))) return rc;
+            if (d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {
+                int active = 1;
+                if ((rc = poll_active(d, &active))) return rc;
+                if (active == 0) { ite++; break; }
+            }
+        }
+    }
+    d->last_iters = ite;
+    /* final _compute_post for every frame (frozen frames recompute the posterior they stopped at) */
+    if ((rc = vn_pass<V, QK_VN_POST>(d, nullptr))) return rc;
+    return QLDPC_OK;
+}
+
+template <int V>
+static int run_layered(qldpc_decoder *d)
+{
+    int rc;
+    const int n_ite = d->cfg.n_ite;
+    const size_t G = (size_t)d->G, FG = (size_t)d->FG;
+    HIPCHK(hipMemcpyAsync(d->d_a, d->d_llr, G * d->N * FG * sizeof(float), hipMemcpyDeviceToDevice, d->stream));   /* var_nodes = Y_N */
+    HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * sizeof(float), d->stream));                                     /* messages = 0   */
+    int ite = 0;
+    const int bx = std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, d->G)));
+    for (; ite < n_ite; ite++) {
+        {
+            prof_scope ps(d, KS_LAYER, bytes_layer(d));
+            for (int l = 0; l < d->n_layers; l++)
+                for (auto &b : d->layer_buckets[(size_t)l]) { launch_layer<V>(d, b); LAUNCHCHK(); }
+        }
+        if (d->cfg.enable_syndrome) {
+            hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N);
+            LAUNCHCHK();
+            if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
+            if ((rc = status_pass<V>(d, ite + 1))) return rc;
+            if (d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {
+                int active = 1;
+                if ((rc = poll_active(d, &active))) return rc;
+                if (active == 0) { ite++; break; }
+            }
+        }
+    }
+    d->last_iters = std::min(ite, n_ite);
+    hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N);
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+template <int V>
+static int run_v(qldpc_decoder *d)
+{
+    {
+        prof_scope ps(d, KS_STATUS, 0.0);
+        hipLaunchKernelGGL((qk_status_init<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->n_frames, d->cfg.n_ite);
+        LAUNCHCHK();
+    }
+    int rc = d->cfg.schedule == QLDPC_SCHED_FLOODING ? run_flooding<V>(d) : run_layered<V>(d);
+    if (rc) return rc;
+    /* success flag: syndrome of the hard decision (all frames) */
+    HIPCHK(hipMemsetAsync(d->d_unsat, 0, sizeof(u64) * (size_t)d->G * V, d->stream));
+    return synd_pass<V>(d, d->d_hard, 0);
+}
+
+extern "C" int qldpc_run(qldpc_decoder *d)
+{
+    if (!d) return QLDPC_EINVAL;
+    if (!d->loaded) { qldpc_set_error("qldpc_run: nothing loaded"); return QLDPC_ESTATE; }
+    HIPCHK(hipSetDevice(d->device));
+    int rc;
+    switch (d->V) {
+    case 1: rc = run_v<1>(d); break;
+    case 2: rc = run_v<2>(d); break;
+    default: rc = run_v<4>(d); break;
+    }
+    if (rc == QLDPC_OK) d->ran = 1;
+    return rc;
+}
+
+/* ------------------------------------------------------------------ load --------------------- */
+
+static int check_frames(qldpc_decoder *d, int n_frames, const char *who)
+{
+    if (n_frames <= 0 || n_frames > d->cfg.max_frames) {
+        qldpc_set_error("%s: n_frames=%d not in [1, max_frames=%d]", who, n_frames, d->cfg.max_frames);
+        return QLDPC_ESIZE;
+    }
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_frames)
+{
+    if (!d || !d_llr) return QLDPC_EINVAL;
+    int rc = check_frames(d, n_frames, "qldpc_load_llr_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    d->n_frames = n_frames;
+    {
+        prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
+        dim3 grid((unsigned)((d->N + 63) / 64), (unsigned)d->G);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_load_llr<1>), grid, dim3(256), 0, d->stream, d_llr, d->d_llr, d->N, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_load_llr<2>), grid, dim3(256), 0, d->stream, d_llr, d->d_llr, d->N, n_frames); break;
+        default: hipLaunchKernelGGL((qk_load_llr<4>), grid, dim3(256), 0, d->stream, d_llr, d->d_llr, d->N, n_frames); break;
+        }
+        LAUNCHCHK();
+    }
+    d->loaded = 1; d->ran = 0;
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, const float *d_llr_mag, const uint8_t *d_vn_class, int n_frames)
+{
+    if (!d || !d_bits || !d_llr_mag) return QLDPC_EINVAL;
+    int rc = check_frames(d, n_frames, "qldpc_load_bits_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    d->n_frames = n_frames;
+    const int W = (d->N + 31) / 32;
+    {
+        prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
+        dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_load_bits<1>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_load_bits<2>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
+        default: hipLaunchKernelGGL((qk_load_bits<4>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
+        }
+        LAUNCHCHK();
+    }
+    d->loaded = 1; d->ran = 0;
+    return QLDPC_OK;
+}
+
+/* ------------------------------------------------------------------ fetch -------------------- */
+
+static int need_ran(qldpc_decoder *d, const char *who)
+{
+    if (!d->ran) { qldpc_set_error("%s: no completed qldpc_run", who); return QLDPC_ESTATE; }
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_fetch_packed_dev(qldpc_decoder *d, uint32_t *d_out)
+{
+    if (!d || !d_out) return QLDPC_EINVAL;
+    int rc = need_ran(d, "qldpc_fetch_packed_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    const int W = (d->N + 31) / 32;
+    prof_scope ps(d, KS_FETCH, (double)W * 4.0 * d->n_frames);
+    dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+    switch (d->V) {
+    case 1: hipLaunchKernelGGL((qk_fetch_packed<1>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
+    case 2: hipLaunchKernelGGL((qk_fetch_packed<2>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
+    default: hipLaunchKernelGGL((qk_fetch_packed<4>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
+    }
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_fetch_info_dev(qldpc_decoder *d, int *d_V_K)
+{
+    if (!d || !d_V_K) return QLDPC_EINVAL;
+    int rc = need_ran(d, "qldpc_fetch_info_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    prof_scope ps(d, KS_FETCH, (double)d->K * 4.0 * d->n_frames);
+    dim3 grid((unsigned)std::max(1, std::min((d->K + 255) / 256, 64)), (unsigned)d->n_frames);
+    switch (d->V) {
+    case 1: hipLaunchKernelGGL((qk_fetch_info<1>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
+    case 2: hipLaunchKernelGGL((qk_fetch_info<2>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
+    default: hipLaunchKernelGGL((qk_fetch_info<4>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
+    }
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_fetch_status_dev(qldpc_decoder *d, int *d_iters, int *d_ok)
+{
+    if (!d) return QLDPC_EINVAL;
+    int rc = need_ran(d, "qldpc_fetch_status_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    dim3 grid((unsigned)((d->n_frames + 255) / 256));
+    switch (d->V) {
+    case 1: hipLaunchKernelGGL((qk_status_out<1>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
+    case 2: hipLaunchKernelGGL((qk_status_out<2>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
+    default: hipLaunchKernelGGL((qk_status_out<4>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
+    }
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+extern "C" int qldpc_fetch_post_dev(qldpc_decoder *d, float *d_post_out)
+{
+    if (!d || !d_post_out) return QLDPC_EINVAL;
+    int rc = need_ran(d, "qldpc_fetch_post_dev");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    const float *src;
+    if (d->cfg.schedule == QLDPC_SCHED_FLOODING) {
+        if (!d->d_post) { if ((rc = dev_alloc(d, &d->d_post, (size_t)d->G * d->N * d->FG))) return rc; }
+        switch (d->V) {
+        case 1: rc = vn_pass<1, QK_VN_POST>(d, d->d_post); break;
+        case 2: rc = vn_pass<2, QK_VN_POST>(d, d->d_post); break;
+        default: rc = vn_pass<4, QK_VN_POST>(d, d->d_post); break;
+        }
+        if (rc) return rc;
+        src = d->d_post;
+    } else {
+        src = d->d_a;
+    }
+    dim3 grid((unsigned)((d->N + 63) / 64), (unsigned)d->G);
+    switch (d->V) {
+    case 1: hipLaunchKernelGGL((qk_unload_f32<1>), grid, dim3(256), 0, d->stream, src, d_post_out, d->N, d->n_frames); break;
+    case 2: hipLaunchKernelGGL((qk_unload_f32<2>), grid, dim3(256), 0, d->stream, src, d_post_out, d->N, d->n_frames); break;
+    default: hipLaunchKernelGGL((qk_unload_f32<4>), grid, dim3(256), 0, d->stream, src, d_post_out, d->N, d->n_frames); break;
+    }
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+/* ------------------------------------------------------------------ AFF3CT mirror ------------ */
+
+/* decoder->decode_siho(LLRs, dec_bits) with host vectors (BS/src/main.cpp:365): H2D, run, D2H. */
+extern "C" int qldpc_decode_siho(qldpc_decoder *d, const float *Y_N, int *V_K, int n_frames)
+{
+    if (!d || !Y_N || !V_K) return QLDPC_EINVAL;
+    int rc = check_frames(d, n_frames, "qldpc_decode_siho");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->device));
+    float *din = nullptr; int *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&din, sizeof(float) * (size_t)n_frames * d->N));
+    if (hipMalloc((void **)&dout, sizeof(int) * (size_t)n_frames * d->K) != hipSuccess) { (void)hipFree(din); qldpc_set_error("decode_siho: hipMalloc failed"); return QLDPC_ENOMEM; }
+    rc = QLDPC_OK;
+    if (hipMemcpyAsync(din, Y_N, sizeof(float) * (size_t)n_frames * d->N, hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = QLDPC_EHIP;
+    if (!rc) rc = qldpc_load_llr_dev(d, din, n_frames);
+    if (!rc) rc = qldpc_run(d);
+    if (!rc) rc = qldpc_fetch_info_dev(d, dout);
+    if (!rc && hipMemcpyAsync(V_K, dout, sizeof(int) * (size_t)n_frames * d->K, hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = QLDPC_EHIP;
+    if (hipStreamSynchronize(d->stream) != hipSuccess && !rc) rc = QLDPC_EHIP;
+    (void)hipFree(din); (void)hipFree(dout);
+    if (rc == QLDPC_EHIP) qldpc_set_error("decode_siho: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
+}

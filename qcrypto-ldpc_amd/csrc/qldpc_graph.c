@@ -1,0 +1,490 @@
+/*
+ * qldpc_graph.c -- H-matrix layer of libqldpc (plain C host code).
+ *
+ * Replaces, for the LDPC path of the reference harness:
+ *   tools::LDPC_matrix_handler::read_matrix_size / read   VAR/main.cpp (alist-v1.0.1):324,338
+ *   .qc reading for Encoder_LDPC_from_QC                   VAR/main.cpp (qc):145
+ *   tools::build_dvbs2 + tools::build_H                    BS/src/main.cpp:175-176  (DVB-like IRA generator)
+ *   H.get_cols_max_degree()                                BS/src/main.cpp:178
+ *   h(), min_cr(), parity_bits_to_punct(), LLR()           BS/src/main.cpp:19-34
+ * (BS = errorcorrection/ldpc_examples/my_project_with_aff3ct/examples/bootstrap, VAR = its
+ * "src/variants (copy out as main.cpp to use)").
+ */
+#define _GNU_SOURCE
+#include "qldpc_graph.h"
+#include "../../include/qldpc.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ errors ------------------- */
+
+static __thread char g_err[512];
+
+void qldpc_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+const char *qldpc_last_error(void) { return g_err; }
+
+const char *qldpc_strerror(int status)
+{
+    switch (status) {
+    case QLDPC_OK: return "ok";
+    case QLDPC_EINVAL: return "invalid argument";
+    case QLDPC_ENOMEM: return "out of memory";
+    case QLDPC_EIO: return "matrix file unreadable or malformed";
+    case QLDPC_EHIP: return "HIP runtime error";
+    case QLDPC_ENODEV: return "no usable HIP device";
+    case QLDPC_ESIZE: return "size mismatch";
+    case QLDPC_EUNSUPPORTED: return "unsupported";
+    case QLDPC_ESTATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+int qldpc_version(void) { return QLDPC_VERSION; }
+
+/* ------------------------------------------------------------------ scalar helpers ----------- */
+
+/* LLR(BER) = -log(BER / (1 - BER)), BS/src/main.cpp:20 (double arithmetic, narrowed like the harness). */
+float qldpc_llr_from_ber(float ber) { return (float)(-log((double)ber / (1.0 - (double)ber))); }
+
+/* Modem_OOK_BSC::set_noise + demodulate (BS/src/main.cpp:317,348): |LLR| = log((1-p)/p) in float. */
+float qldpc_bsc_llr(float ber) { return logf((1.0f - ber) / ber); }
+
+/* h(QBER), BS/src/main.cpp:23 */
+float qldpc_binary_entropy(float q)
+{
+    if (q <= 0.0f || q >= 1.0f) return 0.0f;
+    return (float)((-(double)q) * log2((double)q) - (1.0 - (double)q) * log2(1.0 - (double)q));
+}
+
+/* min_cr(QBER, EFF) = 1 / (1 + EFF * h(QBER)), BS/src/main.cpp:29 */
+float qldpc_min_code_rate(float qber, float efficiency)
+{
+    return (float)(1.0 / (1.0 + (double)efficiency * (double)qldpc_binary_entropy(qber)));
+}
+
+/* parity_bits_to_punct(INFO_B, TTL_B, GOAL_CR) = -((INFO_B) - GOAL_CR * TTL_B) / GOAL_CR, truncated
+ * to int as the harness does (BS/src/main.cpp:34,280). */
+int qldpc_parity_bits_to_punct(int N, int K, float target_cr)
+{
+    return (int)(-((float)K - target_cr * (float)N) / target_cr);
+}
+
+/* ------------------------------------------------------------------ construction ------------- */
+
+void qldpc_code_free(qldpc_code *c)
+{
+    if (!c) return;
+    free(c->cn_ptr); free(c->cn_var); free(c->vn_ptr); free(c->vn_chk); free(c->transpose);
+    free(c->layer_ptr); free(c->layer_order);
+    free(c);
+}
+
+/*
+ * Level schedule for the horizontal-layered decoder: level(c) = 1 + max level of any earlier check
+ * sharing a VN.  Checks of one level are VN-disjoint, and running levels in order is
+ * operation-for-operation the sequential c = 0..M-1 sweep of Decoder_LDPC_BP_horizontal_layered.
+ * When that has (almost) no parallelism -- a dual-diagonal chain makes level(c) = c -- fall back to
+ * a greedy colouring, which is the sequential sweep of a row-permuted H (order exported through
+ * qldpc_code_layer_order so a reference decoder can be given the same row order).
+ */
+static int build_layers(qldpc_code *g)
+{
+    const int N = g->N, M = g->M;
+    int *lvl = (int *)malloc(sizeof(int) * (size_t)M);
+    int *last = (int *)calloc((size_t)N, sizeof(int));
+    if (!lvl || !last) { free(lvl); free(last); return QLDPC_ENOMEM; }
+    int nlev = 0;
+    for (int c = 0; c < M; c++) {
+        int l = 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) if (last[g->cn_var[j]] > l) l = last[g->cn_var[j]];
+        l += 1;
+        lvl[c] = l;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) last[g->cn_var[j]] = l;
+        if (l > nlev) nlev = l;
+    }
+    g->layer_natural = 1;
+    if (nlev > 256 && nlev > M / 16) {
+        /* greedy colouring, first-fit, with a per-VN bitset of used colours */
+        int words = 4;
+        uint64_t *used = (uint64_t *)calloc((size_t)N * words, sizeof(uint64_t));
+        uint64_t *acc = (uint64_t *)malloc(sizeof(uint64_t) * 64);
+        if (!used || !acc) { free(used); free(acc); free(lvl); free(last); return QLDPC_ENOMEM; }
+        nlev = 0;
+        for (int c = 0; c < M; c++) {
+            int col = -1;
+            for (;;) {
+                memset(acc, 0, sizeof(uint64_t) * (size_t)words);
+                for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) {
+                    const uint64_t *u = used + (size_t)g->cn_var[j] * words;
+                    for (int w = 0; w < words; w++) acc[w] |= u[w];
+                }
+                for (int w = 0; w < words && col < 0; w++)
+                    if (~acc[w]) col = w * 64 + __builtin_ctzll(~acc[w]);
+                if (col >= 0) break;
+                if (words >= 64) { free(used); free(acc); free(lvl); free(last); qldpc_set_error("layer colouring needs > 4096 colours"); return QLDPC_EUNSUPPORTED; }
+                /* grow the bitsets */
+                int nw = words * 2;
+                uint64_t *nu = (uint64_t *)calloc((size_t)N * nw, sizeof(uint64_t));
+                if (!nu) { free(used); free(acc); free(lvl); free(last); return QLDPC_ENOMEM; }
+                for (int v = 0; v < N; v++) memcpy(nu + (size_t)v * nw, used + (size_t)v * words, sizeof(uint64_t) * (size_t)words);
+                free(used); used = nu; words = nw;
+            }
+            lvl[c] = col + 1;
+            for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) used[(size_t)g->cn_var[j] * words + col / 64] |= 1ull << (col % 64);
+            if (col + 1 > nlev) nlev = col + 1;
+        }
+        free(used); free(acc);
+        g->layer_natural = 0;
+    }
+    free(last);
+    g->n_layers = nlev;
+    g->layer_ptr = (int *)calloc((size_t)nlev + 1, sizeof(int));
+    g->layer_order = (int *)malloc(sizeof(int) * (size_t)M);
+    if (!g->layer_ptr || !g->layer_order) { free(lvl); return QLDPC_ENOMEM; }
+    for (int c = 0; c < M; c++) g->layer_ptr[lvl[c]]++;
+    for (int l = 0; l < nlev; l++) g->layer_ptr[l + 1] += g->layer_ptr[l];
+    int *fill = (int *)calloc((size_t)nlev, sizeof(int));
+    if (!fill) { free(lvl); return QLDPC_ENOMEM; }
+    for (int c = 0; c < M; c++) { int l = lvl[c] - 1; g->layer_order[g->layer_ptr[l] + fill[l]++] = c; }
+    free(fill); free(lvl);
+    return QLDPC_OK;
+}
+
+static int detect_ira(const qldpc_code *g)
+{
+    /* parity VNs K..N-1 with K = N - M: VN K+c touches exactly checks {c, c+1} (last one only {M-1}) */
+    const int K = g->N - g->M;
+    if (K <= 0) return 0;
+    for (int c = 0; c < g->M; c++) {
+        const int v = K + c, d = g->vn_ptr[v + 1] - g->vn_ptr[v];
+        const int *s = g->vn_chk + g->vn_ptr[v];
+        if (c < g->M - 1) { if (d != 2 || s[0] != c || s[1] != c + 1) return 0; }
+        else if (d != 1 || s[0] != c) return 0;
+    }
+    return K;
+}
+
+int qldpc_code_from_edges(int N, int M, int E, const int *var, const int *chk, qldpc_code **out)
+{
+    if (!out) return QLDPC_EINVAL;
+    *out = NULL;
+    if (N <= 0 || M <= 0 || E <= 0 || !var || !chk) { qldpc_set_error("code_from_edges: bad sizes N=%d M=%d E=%d", N, M, E); return QLDPC_EINVAL; }
+    qldpc_code *g = (qldpc_code *)calloc(1, sizeof(*g));
+    if (!g) return QLDPC_ENOMEM;
+    g->N = N; g->M = M; g->E = E;
+    g->cn_ptr = (int *)calloc((size_t)M + 1, sizeof(int));
+    g->vn_ptr = (int *)calloc((size_t)N + 1, sizeof(int));
+    g->cn_var = (int *)malloc(sizeof(int) * (size_t)E);
+    g->vn_chk = (int *)malloc(sizeof(int) * (size_t)E);
+    g->transpose = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!g->cn_ptr || !g->vn_ptr || !g->cn_var || !g->vn_chk || !g->transpose) { qldpc_code_free(g); return QLDPC_ENOMEM; }
+    for (int e = 0; e < E; e++) {
+        if (var[e] < 0 || var[e] >= N || chk[e] < 0 || chk[e] >= M) {
+            qldpc_set_error("code_from_edges: edge %d = (%d,%d) out of range", e, var[e], chk[e]);
+            qldpc_code_free(g);
+            return QLDPC_EINVAL;
+        }
+        g->cn_ptr[chk[e] + 1]++;
+        g->vn_ptr[var[e] + 1]++;
+    }
+    for (int c = 0; c < M; c++) { if (g->cn_ptr[c + 1] > g->max_dc) g->max_dc = g->cn_ptr[c + 1]; g->cn_ptr[c + 1] += g->cn_ptr[c]; }
+    for (int v = 0; v < N; v++) { if (g->vn_ptr[v + 1] > g->max_dv) g->max_dv = g->vn_ptr[v + 1]; g->vn_ptr[v + 1] += g->vn_ptr[v]; }
+    int *cur = (int *)calloc((size_t)(M > N ? M : N), sizeof(int));
+    if (!cur) { qldpc_code_free(g); return QLDPC_ENOMEM; }
+    for (int e = 0; e < E; e++) g->cn_var[g->cn_ptr[chk[e]] + cur[chk[e]]++] = var[e];
+    memset(cur, 0, sizeof(int) * (size_t)(M > N ? M : N));
+    /* VN slots are handed out while sweeping checks in ascending order (flooding-decoder `transpose`) */
+    for (int c = 0; c < M; c++)
+        for (int k = g->cn_ptr[c]; k < g->cn_ptr[c + 1]; k++) {
+            const int v = g->cn_var[k];
+            const int slot = g->vn_ptr[v] + cur[v]++;
+            g->transpose[k] = slot;
+            g->vn_chk[slot] = c;
+        }
+    free(cur);
+    /* duplicate edges inside a check would make messages alias */
+    for (int v = 0; v < N; v++)
+        for (int s = g->vn_ptr[v] + 1; s < g->vn_ptr[v + 1]; s++)
+            if (g->vn_chk[s] == g->vn_chk[s - 1]) {
+                qldpc_set_error("code_from_edges: duplicate edge (var %d, chk %d)", v, g->vn_chk[s]);
+                qldpc_code_free(g);
+                return QLDPC_EINVAL;
+            }
+    g->ira_K = detect_ira(g);
+    int rc = build_layers(g);
+    if (rc != QLDPC_OK) { qldpc_code_free(g); return rc; }
+    *out = g;
+    return QLDPC_OK;
+}
+
+/* MacKay alist: "N M" / max degrees / VN degrees / CN degrees / N VN lists (1-based, 0-padded) / M CN lists. */
+int qldpc_code_from_alist(const char *path, qldpc_code **out)
+{
+    if (!out || !path) return QLDPC_EINVAL;
+    *out = NULL;
+    FILE *f = fopen(path, "r");
+    if (!f) { qldpc_set_error("alist: cannot open %s", path); return QLDPC_EIO; }
+    int N = 0, M = 0, a = 0, b = 0, rc = QLDPC_EIO;
+    int *dv = NULL, *dc = NULL, *var = NULL, *chk = NULL;
+    char *line = NULL; size_t cap = 0;
+    if (fscanf(f, "%d %d %d %d", &N, &M, &a, &b) != 4 || N <= 0 || M <= 0) { qldpc_set_error("alist: bad header in %s", path); goto done; }
+    dv = (int *)malloc(sizeof(int) * (size_t)N); dc = (int *)malloc(sizeof(int) * (size_t)M);
+    if (!dv || !dc) { rc = QLDPC_ENOMEM; goto done; }
+    long E = 0, Ec = 0;
+    for (int v = 0; v < N; v++) { if (fscanf(f, "%d", &dv[v]) != 1 || dv[v] < 0) { qldpc_set_error("alist: bad VN degree list"); goto done; } E += dv[v]; }
+    for (int c = 0; c < M; c++) { if (fscanf(f, "%d", &dc[c]) != 1 || dc[c] < 0) { qldpc_set_error("alist: bad CN degree list"); goto done; } Ec += dc[c]; }
+    if (E != Ec || E <= 0 || E > 0x7fffffff) { qldpc_set_error("alist: degree sums differ (%ld vs %ld)", E, Ec); goto done; }
+    var = (int *)malloc(sizeof(int) * (size_t)E); chk = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!var || !chk) { rc = QLDPC_ENOMEM; goto done; }
+    { int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {} }
+    long e = 0;
+    for (int v = 0; v < N; v++) {
+        if (getline(&line, &cap, f) < 0) { qldpc_set_error("alist: truncated VN part"); goto done; }
+        int got = 0;
+        for (char *p = line;;) {
+            char *end; long x = strtol(p, &end, 10);
+            if (end == p) break;
+            p = end;
+            if (x == 0) continue;
+            if (x < 0 || x > M || e >= E) { qldpc_set_error("alist: VN %d lists check %ld", v, x); goto done; }
+            var[e] = v; chk[e] = (int)x - 1; e++; got++;
+        }
+        if (got != dv[v]) { qldpc_set_error("alist: VN %d has %d entries, degree says %d", v, got, dv[v]); goto done; }
+    }
+    for (int c = 0; c < M; c++) {
+        if (getline(&line, &cap, f) < 0) { qldpc_set_error("alist: truncated CN part"); goto done; }
+        int got = 0;
+        for (char *p = line;;) { char *end; long x = strtol(p, &end, 10); if (end == p) break; p = end; if (x > 0) got++; }
+        if (got != dc[c]) { qldpc_set_error("alist: CN %d has %d entries, degree says %d", c, got, dc[c]); goto done; }
+    }
+    rc = qldpc_code_from_edges(N, M, (int)E, var, chk, out);
+done:
+    free(line); free(dv); free(dc); free(var); free(chk); fclose(f);
+    return rc;
+}
+
+/* AFF3CT .qc: "cols rows Z", then rows x cols shifts; -1 = zero block, s = identity right-shifted by s. */
+int qldpc_code_from_qc(const char *path, qldpc_code **out)
+{
+    if (!out || !path) return QLDPC_EINVAL;
+    *out = NULL;
+    FILE *f = fopen(path, "r");
+    if (!f) { qldpc_set_error("qc: cannot open %s", path); return QLDPC_EIO; }
+    int nb = 0, mb = 0, Z = 0;
+    if (fscanf(f, "%d %d %d", &nb, &mb, &Z) != 3 || nb <= 0 || mb <= 0 || Z <= 0) { fclose(f); qldpc_set_error("qc: bad header in %s", path); return QLDPC_EIO; }
+    int *B = (int *)malloc(sizeof(int) * (size_t)nb * mb);
+    if (!B) { fclose(f); return QLDPC_ENOMEM; }
+    long blocks = 0;
+    for (long i = 0; i < (long)nb * mb; i++) {
+        if (fscanf(f, "%d", &B[i]) != 1 || B[i] < -1) { free(B); fclose(f); qldpc_set_error("qc: bad entry %ld", i); return QLDPC_EIO; }
+        if (B[i] >= 0) blocks++;
+    }
+    fclose(f);
+    const long E = blocks * Z;
+    if (E <= 0 || E > 0x7fffffff) { free(B); qldpc_set_error("qc: empty or oversized matrix"); return QLDPC_EIO; }
+    int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!var || !chk) { free(B); free(var); free(chk); return QLDPC_ENOMEM; }
+    long e = 0;
+    for (int i = 0; i < mb; i++)
+        for (int j = 0; j < nb; j++) {
+            const int s = B[(long)i * nb + j];
+            if (s < 0) continue;
+            for (int z = 0; z < Z; z++, e++) { chk[e] = i * Z + z; var[e] = j * Z + (z + s) % Z; }
+        }
+    int rc = qldpc_code_from_edges(nb * Z, mb * Z, (int)E, var, chk, out);
+    free(B); free(var); free(chk);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ IRA generator ------------ */
+
+static uint64_t splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+typedef struct { uint64_t s[4]; } xoshiro;
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static uint64_t xo_next(xoshiro *r)
+{
+    const uint64_t res = rotl64(r->s[1] * 5, 7) * 9, t = r->s[1] << 17;
+    r->s[2] ^= r->s[0]; r->s[3] ^= r->s[1]; r->s[1] ^= r->s[2]; r->s[0] ^= r->s[3];
+    r->s[2] ^= t; r->s[3] = rotl64(r->s[3], 45);
+    return res;
+}
+static uint64_t xo_below(xoshiro *r, uint64_t n)   /* unbiased, n >= 1 */
+{
+    const uint64_t lim = UINT64_MAX - UINT64_MAX % n;
+    uint64_t x;
+    do x = xo_next(r); while (x >= lim);
+    return x % n;
+}
+
+int qldpc_code_ira(int N, int K, float hi_frac, int dv_hi, int dv_lo, uint64_t seed, qldpc_code **out)
+{
+    if (!out) return QLDPC_EINVAL;
+    *out = NULL;
+    const int M = N - K;
+    if (N <= 0 || K <= 0 || M <= 1 || dv_hi < dv_lo || dv_lo < 1 || hi_frac < 0.0f || hi_frac > 1.0f) {
+        qldpc_set_error("code_ira: bad parameters N=%d K=%d", N, K);
+        return QLDPC_EINVAL;
+    }
+    const int n_hi = (int)floor((double)hi_frac * (double)K);
+    long base = (long)n_hi * dv_hi + (long)(K - n_hi) * dv_lo;
+    const long dci = (base + M - 1) / M;           /* info edges per check */
+    long deficit = dci * M - base;                 /* raised one degree at a time on the low-degree VNs */
+    if (dci > K) { qldpc_set_error("code_ira: %ld info edges per check > K", dci); return QLDPC_EINVAL; }
+    const long T = dci * M, E = T + 2L * M - 1;
+    if (E > 0x7fffffff) { qldpc_set_error("code_ira: too many edges"); return QLDPC_EINVAL; }
+    int *deg = (int *)malloc(sizeof(int) * (size_t)K);
+    int *stub = (int *)malloc(sizeof(int) * (size_t)T);
+    int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!deg || !stub || !var || !chk) { free(deg); free(stub); free(var); free(chk); return QLDPC_ENOMEM; }
+    for (int v = 0; v < K; v++) deg[v] = v < n_hi ? dv_hi : dv_lo;
+    for (int v = n_hi; deficit > 0; v++) {          /* wrap over the low-degree VNs if needed */
+        if (v >= K) v = n_hi < K ? n_hi : 0;
+        deg[v]++; deficit--;
+    }
+    long t = 0;
+    for (int v = 0; v < K; v++) for (int d = 0; d < deg[v]; d++) stub[t++] = v;
+    xoshiro rng; uint64_t sm = seed;
+    for (int i = 0; i < 4; i++) rng.s[i] = splitmix64(&sm);
+    for (long i = T - 1; i > 0; i--) { long j = (long)xo_below(&rng, (uint64_t)i + 1); int x = stub[i]; stub[i] = stub[j]; stub[j] = x; }
+    /* duplicate-in-row repair: swap an offending stub with a later one that fits (wrapping around) */
+    int rc = QLDPC_OK;
+    for (int c = 0; c < M && rc == QLDPC_OK; c++) {
+        int *row = stub + (long)c * dci;
+        for (long i = 1; i < dci; i++) {
+            int dup = 0;
+            for (long j = 0; j < i; j++) if (row[j] == row[i]) { dup = 1; break; }
+            if (!dup) continue;
+            long tries = 0, p = (long)c * dci + i;
+            for (long q = (p + 1) % T; tries < T; q = (q + 1) % T, tries++) {
+                const long qc = q / dci;
+                if (qc == c) continue;
+                const int cand = stub[q];
+                int bad = 0;
+                for (long j = 0; j < i; j++) if (row[j] == cand) { bad = 1; break; }          /* cand fits row c?   */
+                if (bad) continue;
+                const int *qrow = stub + qc * dci;
+                for (long j = 0; j < dci; j++) if (qrow + j != stub + q && qrow[j] == row[i]) { bad = 1; break; } /* row[i] fits row qc? */
+                if (bad) continue;
+                stub[q] = row[i]; row[i] = cand;
+                break;
+            }
+            if (tries >= T) { qldpc_set_error("code_ira: could not repair duplicate in check %d", c); rc = QLDPC_EINVAL; break; }
+        }
+    }
+    if (rc == QLDPC_OK) {
+        long e = 0;
+        for (int c = 0; c < M; c++) {
+            /* ascending VN order inside a check, as add_connection() sweeps give it */
+            int *row = stub + (long)c * dci;
+            for (long i = 1; i < dci; i++) { int x = row[i]; long j = i - 1; while (j >= 0 && row[j] > x) { row[j + 1] = row[j]; j--; } row[j + 1] = x; }
+            for (long i = 0; i < dci; i++, e++) { var[e] = row[i]; chk[e] = c; }
+            if (c > 0) { var[e] = K + c - 1; chk[e] = c; e++; }
+            var[e] = K + c; chk[e] = c; e++;
+        }
+        rc = qldpc_code_from_edges(N, M, (int)E, var, chk, out);
+    }
+    free(deg); free(stub); free(var); free(chk);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ accessors ---------------- */
+
+int qldpc_code_n(const qldpc_code *c) { return c ? c->N : QLDPC_EINVAL; }
+int qldpc_code_m(const qldpc_code *c) { return c ? c->M : QLDPC_EINVAL; }
+int qldpc_code_e(const qldpc_code *c) { return c ? c->E : QLDPC_EINVAL; }
+int qldpc_code_max_cn_degree(const qldpc_code *c) { return c ? c->max_dc : QLDPC_EINVAL; }
+int qldpc_code_max_vn_degree(const qldpc_code *c) { return c ? c->max_dv : QLDPC_EINVAL; }
+int qldpc_code_is_ira(const qldpc_code *c) { return c ? (c->ira_K > 0) : QLDPC_EINVAL; }
+
+int qldpc_code_export_edges(const qldpc_code *c, int *var, int *chk)
+{
+    if (!c) return QLDPC_EINVAL;
+    if (var) memcpy(var, c->cn_var, sizeof(int) * (size_t)c->E);
+    if (chk) for (int m = 0; m < c->M; m++) for (int k = c->cn_ptr[m]; k < c->cn_ptr[m + 1]; k++) chk[k] = m;
+    return QLDPC_OK;
+}
+
+int qldpc_code_layer_count(const qldpc_code *c) { return c ? c->n_layers : QLDPC_EINVAL; }
+
+int qldpc_code_layer_order(const qldpc_code *c, int *check_order, int *layer_ptr)
+{
+    if (!c) return QLDPC_EINVAL;
+    if (check_order) memcpy(check_order, c->layer_order, sizeof(int) * (size_t)c->M);
+    if (layer_ptr) memcpy(layer_ptr, c->layer_ptr, sizeof(int) * ((size_t)c->n_layers + 1));
+    return c->layer_natural;
+}
+
+int qldpc_code_syndrome_host(const qldpc_code *c, const int *x, int *s)
+{
+    if (!c || !x) return QLDPC_EINVAL;
+    int w = 0;
+    for (int m = 0; m < c->M; m++) {
+        int p = 0;
+        for (int k = c->cn_ptr[m]; k < c->cn_ptr[m + 1]; k++) p ^= x[c->cn_var[k]] & 1;
+        if (s) s[m] = p;
+        w += p;
+    }
+    return w;
+}
+
+/* ------------------------------------------------------------------ GF(2) systematic form ---- */
+
+/*
+ * Encoder_LDPC_from_H(K, N, H, "IDENTITY", ...) (VAR/main.cpp (alist-v1.0.1):142-145) needs a
+ * generator for an arbitrary H.  Row-reduce H over GF(2), searching pivots in ascending column
+ * order: pivot columns become the parity positions, the rest the info positions, and
+ * x_pivot[j] = XOR over free columns f with A[j][f] = 1 of x_free[f].
+ */
+int qldpc_gf2_systematic(const qldpc_code *g, int **pivots_out, int **free_out, uint64_t **A_out, int *wpr_out)
+{
+    const int N = g->N, M = g->M;
+    const size_t W = ((size_t)N + 63) / 64;
+    if ((double)M * (double)W * 8.0 > 2.0e9) { qldpc_set_error("IDENTITY encoder: H too large for dense elimination (%d x %d)", M, N); return QLDPC_EUNSUPPORTED; }
+    uint64_t *R = (uint64_t *)calloc((size_t)M * W, sizeof(uint64_t));
+    int *piv = (int *)malloc(sizeof(int) * (size_t)M);
+    if (!R || !piv) { free(R); free(piv); return QLDPC_ENOMEM; }
+    for (int m = 0; m < M; m++) for (int k = g->cn_ptr[m]; k < g->cn_ptr[m + 1]; k++) R[(size_t)m * W + g->cn_var[k] / 64] ^= 1ull << (g->cn_var[k] % 64);
+    int r = 0;
+    for (int col = 0; col < N && r < M; col++) {
+        int p = -1;
+        for (int m = r; m < M; m++) if (R[(size_t)m * W + col / 64] >> (col % 64) & 1) { p = m; break; }
+        if (p < 0) continue;
+        if (p != r) for (size_t w = 0; w < W; w++) { uint64_t t = R[(size_t)p * W + w]; R[(size_t)p * W + w] = R[(size_t)r * W + w]; R[(size_t)r * W + w] = t; }
+        for (int m = 0; m < M; m++)
+            if (m != r && (R[(size_t)m * W + col / 64] >> (col % 64) & 1))
+                for (size_t w = col / 64; w < W; w++) R[(size_t)m * W + w] ^= R[(size_t)r * W + w];
+        piv[r++] = col;
+    }
+    const int K = N - r;
+    int *fr = (int *)malloc(sizeof(int) * (size_t)(K > 0 ? K : 1));
+    const int wpr = (K + 63) / 64;
+    uint64_t *A = (uint64_t *)calloc((size_t)r * (wpr > 0 ? wpr : 1), sizeof(uint64_t));
+    if (!fr || !A) { free(R); free(piv); free(fr); free(A); return QLDPC_ENOMEM; }
+    for (int col = 0, pi = 0, fi = 0; col < N; col++) {
+        if (pi < r && piv[pi] == col) { pi++; continue; }
+        fr[fi++] = col;
+    }
+    for (int j = 0; j < r; j++)
+        for (int fi = 0; fi < K; fi++)
+            if (R[(size_t)j * W + fr[fi] / 64] >> (fr[fi] % 64) & 1) A[(size_t)j * wpr + fi / 64] |= 1ull << (fi % 64);
+    free(R);
+    *pivots_out = piv; *free_out = fr; *A_out = A; *wpr_out = wpr;
+    return r;
+}

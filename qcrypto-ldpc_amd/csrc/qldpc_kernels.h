@@ -1,0 +1,692 @@
+/*
+ * qldpc_kernels.h -- gfx950 (CDNA4) device kernels of the batched BP decoder.
+ *
+ * Layout ("frame-interleaved"): frames are packed V per wavefront lane, FG = 64*V frames per group.
+ *   llr  [G][N][FG] f32      channel LLRs
+ *   v2c  [G][E][FG] f32      variable->check messages, VN-major slot order
+ *   c2v  [G][E][FG] f32      check->variable messages, VN-major slot order
+ *   sgn / hard [G][N][V] u64 per-VN ballots over the 64 lanes (bit = lane), one per frame-in-lane
+ * One wavefront works on ONE graph node for FG frames at a time, so every graph index is
+ * wave-uniform (scalar loads) and every message access is a contiguous FG*4-byte row.  The
+ * arithmetic per frame is the scalar sequence of AFF3CT's Decoder_LDPC_BP_flooding /
+ * _horizontal_layered (call sites: BS/src/main.cpp:193,365; VAR/main.cpp (alist-v1.0.1):203-237),
+ * in the same operation order, so fp32 results are bit-identical to a scalar CPU decoder for the
+ * min-sum family.  No MFMA: this is gather / min / xor / add, HBM-bound.
+ */
+#ifndef QLDPC_KERNELS_H
+#define QLDPC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+#define QK_WAVES 4            /* wavefronts per workgroup */
+#define QK_THREADS (QK_WAVES * 64)
+
+/* rule families (template parameter); the member of the family is a wave-uniform runtime value */
+#define QK_FAM_MS 0           /* MS / OMS / NMS                 */
+#define QK_FAM_SPA 1
+#define QK_FAM_LSPA 2
+#define QK_FAM_AMS 3          /* AMS<min | min_star_linear2 | min_star> */
+
+struct qk_rule {
+    int rule;      /* qldpc_rule */
+    float param;
+};
+
+/* ------------------------------------------------------------------ small helpers ------------ */
+
+template <int V> struct qk_vec;
+template <> struct qk_vec<1> { typedef float t; };
+template <> struct qk_vec<2> { typedef float2 t; };
+template <> struct qk_vec<4> { typedef float4 t; };
+
+template <int V> __device__ __forceinline__ void qk_load(float (&d)[V], const float *p)
+{
+    typename qk_vec<V>::t t = *reinterpret_cast<const typename qk_vec<V>::t *>(p);
+    const float *s = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int j = 0; j < V; j++) d[j] = s[j];
+}
+template <int V> __device__ __forceinline__ void qk_store(float *p, const float (&d)[V])
+{
+    typename qk_vec<V>::t t;
+    float *s = reinterpret_cast<float *>(&t);
+#pragma unroll
+    for (int j = 0; j < V; j++) s[j] = d[j];
+    *reinterpret_cast<typename qk_vec<V>::t *>(p) = t;
+}
+/* store only the frames whose bit in keep[j] is set for this lane (frozen = converged frames) */
+template <int V> __device__ __forceinline__ void qk_store_masked(float *p, const float (&d)[V], const bool (&frozen)[V], bool any_frozen)
+{
+    if (!any_frozen) { qk_store<V>(p, d); return; }
+#pragma unroll
+    for (int j = 0; j < V; j++) if (!frozen[j]) p[j] = d[j];
+}
+
+__device__ __forceinline__ uint32_t qk_bits(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float qk_withsign(float mag, uint32_t signbit) { return __uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (signbit & 0x80000000u)); }
+__device__ __forceinline__ float qk_min(float a, float b) { return (b < a) ? b : a; }   /* std::min */
+__device__ __forceinline__ float qk_max(float a, float b) { return (a < b) ? b : a; }   /* std::max */
+
+__device__ __forceinline__ float qk_corr_l2(float x) { float t = 0.6f - 0.24f * fabsf(x); return t > 0.0f ? t : 0.0f; }
+__device__ __forceinline__ float qk_ams_min(int rule, float a, float b)
+{
+    const float m = qk_min(a, b);
+    if (rule == 5) return m;
+    if (rule == 7) return m + logf(1.0f + expf(-(a + b))) - logf(1.0f + expf(-fabsf(a - b)));
+    const float r = m + qk_corr_l2(a + b) - qk_corr_l2(a - b);
+    return r > 0.0f ? r : 0.0f;
+}
+
+/* Per-check accumulator of one frame.  in() is compute_chk_node_in, finish() is end_chk_node_in,
+ * out() is compute_chk_node_out of tools::Update_rule_*. */
+template <int FAM> struct qk_acc;
+
+template <> struct qk_acc<QK_FAM_MS> {
+    uint32_t sign; float min1, min2, cst1, cst2;
+    __device__ __forceinline__ void begin() { sign = 0; min1 = 3.402823466e+38f; min2 = 3.402823466e+38f; }
+    __device__ __forceinline__ void in(float x)
+    {
+        const float a = fabsf(x);
+        sign ^= qk_bits(x);
+        min2 = qk_min(min2, qk_max(a, min1));
+        min1 = qk_min(min1, a);
+    }
+    __device__ __forceinline__ void finish(const qk_rule &r)
+    {
+        if (r.rule == 0)      { cst1 = qk_max(0.0f, min2);           cst2 = qk_max(0.0f, min1); }
+        else if (r.rule == 1) { cst1 = qk_max(0.0f, min2 - r.param); cst2 = qk_max(0.0f, min1 - r.param); }
+        else                  { cst1 = min2 * r.param;               cst2 = min1 * r.param; }
+    }
+    __device__ __forceinline__ float out(float x, const qk_rule &) const
+    {
+        const float a = fabsf(x);
+        return qk_withsign((a == min1) ? cst1 : cst2, sign ^ qk_bits(x));
+    }
+};
+
+template <> struct qk_acc<QK_FAM_SPA> {
+    uint32_t sign; float product;
+    __device__ __forceinline__ void begin() { sign = 0; product = 1.0f; }
+    __device__ __forceinline__ void in(float x) { sign ^= qk_bits(x); product *= tanhf(fabsf(x) * 0.5f); }
+    __device__ __forceinline__ void finish(const qk_rule &) {}
+    __device__ __forceinline__ float out(float x, const qk_rule &) const
+    {
+        float t = product / tanhf(fabsf(x) * 0.5f);
+        t = (t < 1.0f) ? t : 1.0f - 1.1920928955078125e-07f;
+        return qk_withsign(2.0f * atanhf(t), sign ^ qk_bits(x));
+    }
+};
+
+template <> struct qk_acc<QK_FAM_LSPA> {
+    uint32_t sign; float sum;
+    __device__ __forceinline__ static float term(float x)
+    {
+        const float t = tanhf(fabsf(x) * 0.5f);
+        return (t != 0.0f) ? logf(t) : 1.175494351e-38f;
+    }
+    __device__ __forceinline__ void begin() { sign = 0; sum = 0.0f; }
+    __device__ __forceinline__ void in(float x) { sign ^= qk_bits(x); sum += term(x); }
+    __device__ __forceinline__ void finish(const qk_rule &) {}
+    __device__ __forceinline__ float out(float x, const qk_rule &) const
+    {
+        float t = sum - term(x);
+        t = (t != 0.0f) ? expf(t) : 1.0f - 1.1920928955078125e-07f;
+        return qk_withsign(2.0f * atanhf(t), sign ^ qk_bits(x));
+    }
+};
+
+template <> struct qk_acc<QK_FAM_AMS> {
+    uint32_t sign; float mn, delta_min, delta; int rule;
+    __device__ __forceinline__ void begin() { sign = 0; mn = 3.402823466e+38f; delta_min = 3.402823466e+38f; }
+    __device__ __forceinline__ void in_r(float x, int r)
+    {
+        const float a = fabsf(x);
+        sign ^= qk_bits(x);
+        float other;
+        if (a < mn) { other = mn; mn = a; } else other = a;
+        delta_min = qk_ams_min(r, delta_min, other);
+    }
+    __device__ __forceinline__ void finish(const qk_rule &r)
+    {
+        delta = qk_max(0.0f, qk_ams_min(r.rule, delta_min, mn));
+        delta_min = qk_max(0.0f, delta_min);
+    }
+    __device__ __forceinline__ float out(float x, const qk_rule &) const
+    {
+        const float a = fabsf(x);
+        return qk_withsign((a == mn) ? delta_min : delta, sign ^ qk_bits(x));
+    }
+};
+
+template <int FAM> __device__ __forceinline__ void qk_acc_in(qk_acc<FAM> &a, float x, const qk_rule &) { a.in(x); }
+template <> __device__ __forceinline__ void qk_acc_in<QK_FAM_AMS>(qk_acc<QK_FAM_AMS> &a, float x, const qk_rule &r) { a.in_r(x, r.rule); }
+
+/* wave-uniform "all frames of this group have converged" test; done is [G][V] */
+template <int V> __device__ __forceinline__ bool qk_group_done(const u64 *__restrict__ done, int g)
+{
+    bool all = true;
+#pragma unroll
+    for (int j = 0; j < V; j++) all = all && (done[(size_t)g * V + j] == ~0ull);
+    return all;
+}
+template <int V> __device__ __forceinline__ bool qk_frozen(const u64 *__restrict__ done, int g, int lane, bool (&frozen)[V])
+{
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const u64 d = done[(size_t)g * V + j];
+        frozen[j] = (d >> lane) & 1ull;
+        any = any || (d != 0ull);
+    }
+    return any;   /* wave-uniform */
+}
+
+/* ------------------------------------------------------------------ flooding: check nodes ---- */
+
+/*
+ * _decode_single_ite of Decoder_LDPC_BP_flooding: for each check gather var_to_chk through
+ * `transpose`, fold, emit chk_to_var to the same slots.  One wavefront per check, FG frames wide.
+ * DCMAX > 0: messages stay in registers (checks in `list` have degree <= DCMAX).
+ * DCMAX == 0: any degree, second pass re-reads the rows (they are L2-hot).
+ */
+template <int V, int DCMAX, int FAM>
+__global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restrict__ v2c, float *__restrict__ c2v,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    if (qk_group_done<V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bool frozen[V];
+    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
+    const float *vin = v2c + (size_t)g * group_stride + lane * V;
+    float *cout = c2v + (size_t)g * group_stride + lane * V;
+
+    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
+        const int c = list[i];
+        const int b = cn_ptr[c];
+        const int deg = cn_ptr[c + 1] - b;
+        qk_acc<FAM> acc[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].begin();
+        if constexpr (DCMAX > 0) {
+            float x[DCMAX][V];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) qk_load<V>(x[k], vin + (size_t)cn_tr[b + k] * FG);
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
+                }
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[j].finish(rule);
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+                    float o[V];
+#pragma unroll
+                    for (int j = 0; j < V; j++) o[j] = acc[j].out(x[k][j], rule);
+                    qk_store_masked<V>(cout + (size_t)cn_tr[b + k] * FG, o, frozen, any_frozen);
+                }
+        } else {
+            for (int k = 0; k < deg; k++) {
+                float x[V];
+                qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
+#pragma unroll
+                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[j], rule);
+            }
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[j].finish(rule);
+            for (int k = 0; k < deg; k++) {
+                float x[V], o[V];
+                const size_t off = (size_t)cn_tr[b + k] * FG;
+                qk_load<V>(x, vin + off);
+#pragma unroll
+                for (int j = 0; j < V; j++) o[j] = acc[j].out(x[j], rule);
+                qk_store_masked<V>(cout + off, o, frozen, any_frozen);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ flooding: variable nodes - */
+
+#define QK_VN_FIRST 0     /* iteration 0: chk_to_var is all zero (decoder after reset()), not read */
+#define QK_VN_NORMAL 1    /* _initialize_var_to_chk                                               */
+#define QK_VN_POST 2      /* _compute_post only: ballots, optional post store, no var_to_chk       */
+
+/*
+ * _initialize_var_to_chk / _compute_post: sum = 0; sum += chk_to_var[slot] in slot order;
+ * tmp = Y[v] + sum; var_to_chk[slot] = tmp - chk_to_var[slot].  A VN's slots are contiguous rows,
+ * so this kernel streams.  Also emits the per-VN ballots: sgn = signbit(tmp) (what
+ * check_syndrome_soft tests) and hard = !(tmp >= 0) (what decode_siho outputs).
+ */
+template <int V, int DVMAX, int MODE>
+__global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restrict__ c2v, const float *__restrict__ llr,
+                                                          float *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
+                                                          float *__restrict__ post_out,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ vn_ptr, int N, size_t group_stride,
+                                                          const u64 *__restrict__ done)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    if (MODE != QK_VN_POST && qk_group_done<V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *cin = c2v + (size_t)g * group_stride + lane * V;
+    float *vout = v2c + (size_t)g * group_stride + lane * V;
+    const float *yin = llr + (size_t)g * N * FG + lane * V;
+
+    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
+        const int v = list[i];
+        const int b = vn_ptr[v];
+        const int deg = vn_ptr[v + 1] - b;
+        float y[V], sum[V], tmp[V];
+        qk_load<V>(y, yin + (size_t)v * FG);
+#pragma unroll
+        for (int j = 0; j < V; j++) sum[j] = 0.0f;
+        if constexpr (MODE == QK_VN_FIRST) {
+#pragma unroll
+            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; j++) o[j] = tmp[j] - 0.0f;
+            for (int k = 0; k < deg; k++) qk_store<V>(vout + (size_t)(b + k) * FG, o);
+        } else if constexpr (DVMAX > 0) {
+            float m[DVMAX][V];
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++)
+                if (k < deg) qk_load<V>(m[k], cin + (size_t)(b + k) * FG);
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++)
+                if (k < deg) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) sum[j] += m[k][j];
+                }
+#pragma unroll
+            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+            if constexpr (MODE == QK_VN_NORMAL) {
+#pragma unroll
+                for (int k = 0; k < DVMAX; k++)
+                    if (k < deg) {
+                        float o[V];
+#pragma unroll
+                        for (int j = 0; j < V; j++) o[j] = tmp[j] - m[k][j];
+                        qk_store<V>(vout + (size_t)(b + k) * FG, o);
+                    }
+            }
+        } else {
+            for (int k = 0; k < deg; k++) {
+                float m[V];
+                qk_load<V>(m, cin + (size_t)(b + k) * FG);
+#pragma unroll
+                for (int j = 0; j < V; j++) sum[j] += m[j];
+            }
+#pragma unroll
+            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+            if constexpr (MODE == QK_VN_NORMAL) {
+                for (int k = 0; k < deg; k++) {
+                    float m[V], o[V];
+                    qk_load<V>(m, cin + (size_t)(b + k) * FG);
+#pragma unroll
+                    for (int j = 0; j < V; j++) o[j] = tmp[j] - m[j];
+                    qk_store<V>(vout + (size_t)(b + k) * FG, o);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const u64 s = __ballot((qk_bits(tmp[j]) >> 31) != 0);
+            if (lane == 0) sgn[((size_t)g * N + v) * V + j] = s;
+            if constexpr (MODE == QK_VN_POST) {
+                const u64 h = __ballot(!(tmp[j] >= 0.0f));
+                if (lane == 0) hard[((size_t)g * N + v) * V + j] = h;
+            }
+        }
+        if constexpr (MODE == QK_VN_POST) {
+            if (post_out) qk_store<V>(post_out + ((size_t)g * N + v) * FG + lane * V, tmp);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ horizontal layered ------- */
+
+/*
+ * One layer (VN-disjoint checks) of Decoder_LDPC_BP_horizontal_layered::_decode_single_ite:
+ *   contributions[i] = var_nodes[v_i] - messages[k]; fold; messages[k] = out_i;
+ *   var_nodes[v_i] = contributions[i] + messages[k]
+ * msg is CN-major [G][E][FG]; post is [G][N][FG].
+ */
+template <int V, int DCMAX, int FAM>
+__global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ post, float *__restrict__ msg,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
+                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    if (qk_group_done<V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bool frozen[V];
+    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
+    float *pg = post + (size_t)g * N * FG + lane * V;
+    float *mg = msg + (size_t)g * group_stride + lane * V;
+
+    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
+        const int c = list[i];
+        const int b = cn_ptr[c];
+        const int deg = cn_ptr[c + 1] - b;
+        qk_acc<FAM> acc[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].begin();
+        if constexpr (DCMAX > 0) {
+            float x[DCMAX][V];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+                    float p[V], m[V];
+                    qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
+                    qk_load<V>(m, mg + (size_t)(b + k) * FG);
+#pragma unroll
+                    for (int j = 0; j < V; j++) x[k][j] = p[j] - m[j];
+                }
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
+                }
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[j].finish(rule);
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+                    float o[V], p[V];
+#pragma unroll
+                    for (int j = 0; j < V; j++) { o[j] = acc[j].out(x[k][j], rule); p[j] = x[k][j] + o[j]; }
+                    qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
+                    qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
+                }
+        } else {
+            for (int k = 0; k < deg; k++) {
+                float p[V], m[V];
+                qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
+                qk_load<V>(m, mg + (size_t)(b + k) * FG);
+#pragma unroll
+                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], p[j] - m[j], rule);
+            }
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[j].finish(rule);
+            for (int k = 0; k < deg; k++) {
+                float p[V], m[V], o[V];
+                qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
+                qk_load<V>(m, mg + (size_t)(b + k) * FG);
+#pragma unroll
+                for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(x, rule); p[j] = x + o[j]; }
+                qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
+                qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
+            }
+        }
+    }
+}
+
+/* ballots of an explicit posterior array (layered schedule): sgn = signbit, hard = !(p >= 0) */
+template <int V>
+__global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__restrict__ post, u64 *__restrict__ sgn,
+                                                              u64 *__restrict__ hard, int N)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int v = blockIdx.x * QK_WAVES + wave; v < N; v += gridDim.x * QK_WAVES) {
+        float p[V];
+        qk_load<V>(p, post + ((size_t)g * N + v) * FG + lane * V);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
+            const u64 h = __ballot(!(p[j] >= 0.0f));
+            if (lane == 0) { sgn[((size_t)g * N + v) * V + j] = s; hard[((size_t)g * N + v) * V + j] = h; }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ syndrome + status -------- */
+
+/* check_syndrome_soft for FG frames at once: XOR the VN ballots of each check, OR over checks. */
+template <int V>
+__global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_ptr,
+                                                   const int *__restrict__ cn_var, int M, int N,
+                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done)
+{
+    const int g = blockIdx.y;
+    if (skip_done && qk_group_done<V>(done, g)) return;
+    const u64 *mg = mask + (size_t)g * N * V;
+    u64 acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = 0;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < M; c += gridDim.x * blockDim.x) {
+        u64 s[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) s[j] = 0;
+        for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++) {
+            const u64 *p = mg + (size_t)cn_var[k] * V;
+#pragma unroll
+            for (int j = 0; j < V; j++) s[j] ^= p[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] |= s[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        u64 a = acc[j];
+        for (int o = 32; o > 0; o >>= 1) a |= __shfl_xor(a, o);
+        if ((threadIdx.x & 63) == 0 && a) atomicOr(&unsat[(size_t)g * V + j], a);
+    }
+}
+
+/* per-frame bookkeeping after a syndrome pass: AFF3CT's cur_syndrome_depth logic, done bits,
+ * iteration counts; clears unsat for the next pass; counts groups still active. */
+template <int V>
+__global__ void qk_status(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
+                          int G, int syndrome_depth, int ite_done /* iterations executed so far */, int *__restrict__ active_groups)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;   /* 64 threads */
+    bool all = true;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const u64 u = unsat[(size_t)g * V + j];
+        const u64 d = done[(size_t)g * V + j];
+        const int f = g * FG + lane * V + j;
+        const bool was_done = (d >> lane) & 1ull;
+        const bool zero = !((u >> lane) & 1ull);
+        bool now = false;
+        if (!was_done) {
+            int cur = depth[f];
+            cur = zero ? (cur + 1) % syndrome_depth : 0;
+            depth[f] = cur;
+            now = zero && cur == 0;
+            if (now) iters[f] = ite_done;
+        }
+        const u64 nd = d | __ballot(now);
+        all = all && (nd == ~0ull);
+        if (lane == 0) { done[(size_t)g * V + j] = nd; unsat[(size_t)g * V + j] = 0; }
+    }
+    if (lane == 0 && !all) atomicAdd(active_groups, 1);
+    (void)G;
+}
+
+template <int V>
+__global__ void qk_status_init(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
+                               int n_frames, int n_ite)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const int f = g * FG + lane * V + j;
+        depth[f] = 0;
+        iters[f] = n_ite;
+        const u64 pad = __ballot(f >= n_frames);   /* padding frames never run */
+        if (lane == 0) { done[(size_t)g * V + j] = pad; unsat[(size_t)g * V + j] = 0; }
+    }
+}
+
+/* ok[f] = !(unsat bit) after a syndrome pass over the hard ballots; iters copied out */
+template <int V>
+__global__ void qk_status_out(const u64 *__restrict__ unsat, const int *__restrict__ iters, int *__restrict__ out_iters,
+                              int *__restrict__ out_ok, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const int g = f / FG, r = f % FG, lane = r / V, j = r % V;
+    if (out_iters) out_iters[f] = iters[f];
+    if (out_ok) out_ok[f] = !((unsat[(size_t)g * V + j] >> lane) & 1ull);
+}
+
+/* ------------------------------------------------------------------ load / fetch ------------- */
+
+/* [n_frames][N] frame-major floats -> [G][N][FG]; padding frames get +1 (all-zero word, benign) */
+template <int V>
+__global__ __launch_bounds__(256) void qk_load_llr(const float *__restrict__ src, float *__restrict__ dst, int N, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    __shared__ float tile[64][65];
+    const int g = blockIdx.y, v0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   /* 4 rows at a time */
+    for (int r0 = 0; r0 < FG; r0 += 64) {
+        for (int r = ty; r < 64; r += 4) {
+            const int f = g * FG + r0 + r, v = v0 + tx;
+            tile[r][tx] = (f < n_frames && v < N) ? src[(size_t)f * N + v] : 1.0f;
+        }
+        __syncthreads();
+        for (int vv = ty; vv < 64; vv += 4) {
+            const int v = v0 + vv;
+            if (v < N) dst[((size_t)g * N + v) * FG + r0 + tx] = tile[tx][vv];
+        }
+        __syncthreads();
+    }
+}
+
+/* [G][N][FG] -> [n_frames][N] (posterior read-back for tests) */
+template <int V>
+__global__ __launch_bounds__(256) void qk_unload_f32(const float *__restrict__ src, float *__restrict__ dst, int N, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    __shared__ float tile[64][65];
+    const int g = blockIdx.y, v0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r0 = 0; r0 < FG; r0 += 64) {
+        for (int vv = ty; vv < 64; vv += 4) {
+            const int v = v0 + vv;
+            tile[vv][tx] = (v < N) ? src[((size_t)g * N + v) * FG + r0 + tx] : 0.0f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {
+            const int f = g * FG + r0 + r, v = v0 + tx;
+            if (f < n_frames && v < N) dst[(size_t)f * N + v] = tile[tx][r];
+        }
+        __syncthreads();
+    }
+}
+
+/*
+ * QKD frame formation (BS/src/main.cpp:348-362): packed sifted-key words + per-frame |LLR| (the
+ * host computes ln((1-p)/p) from the estimated QBER, so no device log is involved) ->
+ * LLR = (1 - 2y) * |LLR| at channel VNs, +-23.02585 at pinned VNs, 0 at punctured VNs.
+ * bits[n_frames][W] MSB-first (helpers.h:65-70).  One wavefront = 64 lanes x V frames, 32 VNs per word.
+ */
+template <int V>
+__global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag,
+                                                           const uint8_t *__restrict__ vn_class, float *__restrict__ dst,
+                                                           int N, int W, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float mag[V];
+    bool live[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const int f = g * FG + lane * V + j;
+        live[j] = f < n_frames;
+        mag[j] = live[j] ? llr_mag[f] : 1.0f;
+    }
+    for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
+        uint32_t word[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) word[j] = live[j] ? bits[(size_t)(g * FG + lane * V + j) * W + w] : 0u;
+        for (int b = 0; b < 32; b++) {
+            const int v = w * 32 + b;
+            if (v >= N) break;
+            const int cls = vn_class ? vn_class[v] : 0;
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const bool y = (word[j] >> (31 - b)) & 1u;
+                const float m = (cls == 0) ? mag[j] : (cls == 1 ? 23.025850929840455f : 0.0f);
+                o[j] = live[j] ? (y ? -m : m) : 1.0f;
+            }
+            qk_store<V>(dst + ((size_t)g * N + v) * FG + lane * V, o);
+        }
+    }
+}
+
+/* hard ballots -> packed MSB-first words out[n_frames][W] */
+template <int V>
+__global__ __launch_bounds__(QK_THREADS) void qk_fetch_packed(const u64 *__restrict__ hard, uint32_t *__restrict__ out,
+                                                              int N, int W, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
+        uint32_t word[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) word[j] = 0;
+        for (int b = 0; b < 32; b++) {
+            const int v = w * 32 + b;
+            if (v >= N) break;
+#pragma unroll
+            for (int j = 0; j < V; j++) word[j] |= (uint32_t)((hard[((size_t)g * N + v) * V + j] >> lane) & 1ull) << (31 - b);
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const int f = g * FG + lane * V + j;
+            if (f < n_frames) out[(size_t)f * W + w] = word[j];
+        }
+    }
+}
+
+/* hard ballots -> V_K[n_frames][K] ints at info_bits_pos (decode_siho's output layout) */
+template <int V>
+__global__ __launch_bounds__(256) void qk_fetch_info(const u64 *__restrict__ hard, const int *__restrict__ info_pos,
+                                                     int *__restrict__ out, int N, int K, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int f = blockIdx.y;
+    const int g = f / FG, r = f % FG, lane = r / V, j = r % V;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+        const int v = info_pos[i];
+        out[(size_t)f * K + i] = (int)((hard[((size_t)g * N + v) * V + j] >> lane) & 1ull);
+    }
+    (void)n_frames;
+}
+
+#endif /* QLDPC_KERNELS_H */

@@ -1,0 +1,173 @@
+"""CPU suite: host logic of libqldpc (graph layer, scalar helpers, C ABI surface). No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(q):
+    hdr = open(os.path.join(ROOT, "include", "qldpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(qldpc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 45
+    lib = ctypes.CDLL(q.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_and_strerror(q):
+    assert q.version() == 100
+    assert q._L.qldpc_strerror(-6) == b"size mismatch"
+
+
+def test_scalar_helpers_follow_the_harness_macros(q):
+    # BS/src/main.cpp:19-34
+    assert abs(q.llr_from_ber(0.02) - (-np.log(0.02 / 0.98))) < 1e-6
+    assert abs(q.bsc_llr(0.02) - np.log(np.float32(0.98) / np.float32(0.02))) < 1e-6
+    assert abs(q.CONFIRMED_BIT_LLR - (-np.log(1e-10 / (1 - 1e-10)))) < 1e-12
+    h = -0.02 * np.log2(0.02) - 0.98 * np.log2(0.98)
+    assert abs(q.binary_entropy(0.02) - h) < 1e-6
+    assert abs(q.min_code_rate(0.02, 1.4) - 1 / (1 + 1.4 * h)) < 1e-6
+    # parity_bits_to_punct(INFO_B, TTL_B, GOAL_CR) = -((INFO_B) - GOAL_CR*TTL_B)/GOAL_CR, truncated
+    assert q.parity_bits_to_punct(64800, 48600, 0.8) == int(-(48600 - 0.8 * 64800) / 0.8)
+    # README_LDPC.md:900-935 table row: QBER 2 % -> Shannon CR 0.8761
+    assert abs(q.min_code_rate(0.02, 1.0) - 0.8761) < 5e-4
+
+
+def test_alist_graph_matches_oracle_graph(q, O, gold):
+    p = os.path.join(gold, "PEGReg504x1008.alist")
+    c, g = q.Code.from_alist(p), O.Graph.from_alist(p)
+    assert (c.N, c.M, c.E, c.max_cn_degree, c.max_vn_degree) == (g.N, g.M, g.E, g.max_dc, g.max_dv)
+    var, chk = c.edges()
+    ovar, ochk = g.edges()
+    assert (var == ovar).all() and (chk == ochk).all()
+
+
+@pytest.mark.parametrize("name", ["test2.qc", "NR_2_3_112.qc", "NR_1_0_2.qc"])
+def test_qc_graph_matches_oracle_graph(q, O, gold, name):
+    p = os.path.join(gold, name)
+    c, g = q.Code.from_qc(p), O.Graph.from_qc(p)
+    var, chk = c.edges()
+    ovar, ochk = g.edges()
+    assert (var == ovar).all() and (chk == ochk).all()
+
+
+def test_bad_files_return_codes(q, tmp_path):
+    with pytest.raises(q.QldpcError) as e:
+        q.Code.from_alist(str(tmp_path / "nope.alist"))
+    assert e.value.status == -3
+    bad = tmp_path / "bad.alist"
+    bad.write_text("4 2\n2 2\n1 1 1 1\n2 2\n1\n2\n1\n9\n1 3\n2 4\n")
+    with pytest.raises(q.QldpcError):
+        q.Code.from_alist(str(bad))
+    with pytest.raises(q.QldpcError) as e:
+        q.Code.from_edges(4, 2, [0, 0], [0, 0])          # duplicate edge
+    assert e.value.status == -1
+
+
+def test_ira_config2_shape(q):
+    # SURVEY.md section 8d, config 2
+    c = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
+    assert (c.N, c.M, c.E) == (65536, 13107, 235925)
+    assert c.max_cn_degree == 18 and c.max_vn_degree == 11 and c.is_ira
+    var, chk = c.edges()
+    dv = np.bincount(var, minlength=c.N)
+    dc = np.bincount(chk, minlength=c.M)
+    assert (dv[:6553] == 11).all() and (dv[6553] == 4) and (dv[6554:52429] == 3).all()
+    assert (dv[52429:-1] == 2).all() and dv[-1] == 1
+    assert dc[0] == 17 and (dc[1:] == 18).all()
+    # no duplicate edges, deterministic in the seed
+    assert len(set(zip(var.tolist(), chk.tolist()))) == c.E
+    v2, c2 = q.Code.ira(65536, 52429, 0.125, 11, 3, 7).edges()
+    assert (v2 == var).all() and (c2 == chk).all()
+    v3, _ = q.Code.ira(65536, 52429, 0.125, 11, 3, 8).edges()
+    assert (v3 != var).any()
+
+
+@pytest.mark.parametrize("rate", [0.5, 0.7, 0.8, 0.9])
+def test_ira_multi_rate_set(q, rate):
+    N = 8192
+    K = int(round(N * rate))
+    c = q.Code.ira(N, K, 0.125, 11, 3, 7)
+    var, chk = c.edges()
+    dc = np.bincount(chk, minlength=c.M)
+    assert c.is_ira and dc[1:].min() == dc[1:].max()
+    assert len(set(zip(var.tolist(), chk.tolist()))) == c.E
+
+
+def test_layer_order_is_a_valid_schedule(q, gold):
+    for c in (q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist")), q.Code.from_qc(os.path.join(gold, "NR_2_3_112.qc")),
+              q.Code.ira(4096, 3277)):
+        order, ptr, natural = c.layer_order()
+        assert sorted(order.tolist()) == list(range(c.M)) and ptr[0] == 0 and ptr[-1] == c.M
+        var, chk = c.edges()
+        vs = [set() for _ in range(c.M)]
+        for v, m in zip(var.tolist(), chk.tolist()):
+            vs[m].add(v)
+        for l in range(c.n_layers):            # checks of a layer share no variable node
+            seen = set()
+            for m in order[ptr[l]:ptr[l + 1]]:
+                assert not (seen & vs[m])
+                seen |= vs[m]
+        if natural:                            # level schedule: conflicting checks keep their c-order
+            where = np.empty(c.M, int)
+            for l in range(c.n_layers):
+                where[order[ptr[l]:ptr[l + 1]]] = l
+            last = {}
+            for m in range(c.M):
+                for v in vs[m]:
+                    if v in last:
+                        assert where[last[v]] < where[m]
+                    last[v] = m
+
+
+def test_qc_natural_layers_are_block_rows(q, gold):
+    c = q.Code.from_qc(os.path.join(gold, "NR_2_3_112.qc"))     # 42 block rows, Z = 112
+    _, _, natural = c.layer_order()
+    assert natural and c.n_layers <= 42
+
+
+def test_syndrome_host_and_kat(q, gold):
+    import json
+    kat = json.load(open(os.path.join(gold, "kat_peg504x1008.json")))
+    c = q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist"))
+    assert c.syndrome(kat["encoded"])[0] == 0
+    x = list(kat["encoded"])
+    x[7] ^= 1
+    assert c.syndrome(x)[0] == 3                     # a degree-3 VN flips 3 checks
+
+
+def test_pack_unpack_is_msb_first(q):
+    # helpers.h:65-70: bit i <-> word[i/32] & (1 << (31 - i%32))
+    bits = np.zeros(70, np.uint8)
+    bits[[0, 33, 69]] = 1
+    w = q.pack_bits(bits)
+    assert w.tolist() == [1 << 31, 1 << 30, 1 << (31 - 5)]
+    assert (q.unpack_bits(w, 70) == bits).all()
+
+
+def test_decoder_without_gpu_fails_loudly(q, gold):
+    if q.device_count() > 0:
+        pytest.skip("GPU present")
+    c = q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist"))
+    with pytest.raises(q.QldpcError) as e:
+        q.Decoder(c, 504, 10)
+    assert e.value.status == -5 and "no CPU fallback" in str(e.value)
+    with pytest.raises(q.QldpcError):
+        q.Encoder(c, "IDENTITY")
+
+
+def test_decoder_argument_checks_come_before_the_device(q, gold):
+    c = q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist"))
+    for kw, status in ((dict(K=0), -6), (dict(K=2000), -6), (dict(n_ite=0), -1), (dict(n_frames=0), -1), (dict(syndrome_depth=0), -1),
+                       (dict(frames_per_lane=3), -1)):
+        args = dict(K=504, n_ite=10, n_frames=1, syndrome_depth=1, frames_per_lane=0)
+        args.update(kw)
+        with pytest.raises(q.QldpcError) as e:
+            q.Decoder(c, args["K"], args["n_ite"], n_frames=args["n_frames"], syndrome_depth=args["syndrome_depth"],
+                      frames_per_lane=args["frames_per_lane"])
+        assert e.value.status == status, kw

@@ -1,0 +1,104 @@
+"""CPU suite: the oracle against every pin the reference holds for the LDPC path.
+
+Pins: the commented-out known-answer vectors in
+VAR/main.cpp (alist-v1.0.1):445,447,456,460 on BS/matrices/H/PEGReg504x1008.alist, decoder
+'BP flooding SPA', n_ite = 10, syndrome on, depth 1 (:39-41,:454).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def kat(gold):
+    return json.load(open(os.path.join(gold, "kat_peg504x1008.json")))
+
+
+@pytest.fixture(scope="module")
+def peg(O, gold):
+    return O.Graph.from_alist(os.path.join(gold, "PEGReg504x1008.alist"))
+
+
+def test_alist_shape(peg):
+    assert (peg.N, peg.M, peg.E, peg.max_dv, peg.max_dc) == (1008, 504, 3024, 3, 8)
+
+
+def test_kat_encoded_is_codeword(peg, kat):
+    w, _ = peg.syndrome(kat["encoded"])
+    assert w == 0
+    assert kat["data"] == kat["encoded"][504:]          # info_bits_pos = 504..1007
+
+
+def test_kat_flooding_spa_exact(O, peg, kat):
+    r = O.decode(peg, np.array(kat["llrs"], np.float32), "SPA", 0.0, 10, "flooding", True, 1)
+    assert r["iters"][0] == 6                            # converges at the 6th iteration, before n_ite
+    assert r["synd_ok"][0] == 1
+    assert (r["hard"][0][504:] == np.array(kat["decoded"])).all()
+    raw = (np.array(kat["llrs"]) < 0).astype(int)[504:]
+    assert (raw != np.array(kat["decoded"])).sum() == 32  # a non-trivial decode: 32 channel errors fixed
+
+
+@pytest.mark.parametrize("rule,param,sched", [("NMS", 0.75, "flooding"), ("OMS", 0.5, "flooding"), ("MS", 0.0, "flooding"),
+                                              ("MS", 0.0, "hlayered"), ("NMS", 0.75, "hlayered"), ("SPA", 0.0, "hlayered"),
+                                              ("LSPA", 0.0, "flooding"), ("AMS_MINSTAR", 0.0, "flooding"),
+                                              ("AMS_MINSTAR_L2", 0.0, "flooding"), ("AMS_MIN", 0.0, "flooding")])
+def test_kat_other_rules_reach_same_word(O, peg, kat, rule, param, sched):
+    r = O.decode(peg, np.array(kat["llrs"], np.float32), rule, param, 50, sched)
+    assert r["synd_ok"][0] == 1 and r["iters"][0] < 50
+    assert (r["hard"][0][504:] == np.array(kat["decoded"])).all()
+
+
+def test_syndrome_disabled_runs_all_iterations(O, peg, kat):
+    r = O.decode(peg, np.array(kat["llrs"], np.float32), "SPA", 0.0, 10, "flooding", False, 1)
+    assert r["iters"][0] == 10
+    assert (r["hard"][0][504:] == np.array(kat["decoded"])).all()
+
+
+def test_syndrome_depth_two_needs_one_more_iteration(O, peg, kat):
+    r1 = O.decode(peg, np.array(kat["llrs"], np.float32), "SPA", 0.0, 10, "flooding", True, 1)
+    r2 = O.decode(peg, np.array(kat["llrs"], np.float32), "SPA", 0.0, 10, "flooding", True, 2)
+    assert r2["iters"][0] == r1["iters"][0] + 1
+
+
+def test_last_iteration_is_not_checked(O, peg, kat):
+    # AFF3CT skips the syndrome test on ite == n_ite-1: with n_ite = 6 the loop runs out instead of breaking
+    r = O.decode(peg, np.array(kat["llrs"], np.float32), "SPA", 0.0, 6, "flooding", True, 1)
+    assert r["iters"][0] == 6 and r["synd_ok"][0] == 1
+
+
+def test_qc_convention(O, gold):
+    # test2.qc: 18 x 6 blocks of Z = 7 (EC/ldpc_examples/README.md:7); shift s puts row r's 1 at column (r+s)%Z
+    g = O.Graph.from_qc(os.path.join(gold, "test2.qc"))
+    assert (g.N, g.M) == (126, 42)
+    ex = g.export()
+    row0 = sorted(ex["cn_var"][ex["cn_ptr"][0]:ex["cn_ptr"][1]].tolist())
+    # first base row: 564 -1 276 -1 522 -1 404 -1 579 -1 332 -1 0 -1 ...  -> columns j*7 + (0 + s) % 7
+    exp = sorted([0 * 7 + 564 % 7, 2 * 7 + 276 % 7, 4 * 7 + 522 % 7, 6 * 7 + 404 % 7, 8 * 7 + 579 % 7, 10 * 7 + 332 % 7, 12 * 7 + 0])
+    assert row0 == exp
+
+
+@pytest.mark.parametrize("name,shape", [("20.alist", (504, 252)), ("1998.5.3.2665.alist", (1998, 222))])
+def test_other_alists_parse(O, gold, name, shape):
+    g = O.Graph.from_alist(os.path.join(gold, name))
+    assert (g.N, g.M) == shape
+    ex = g.export()
+    assert ex["vn_ptr"][-1] == g.E and ex["cn_ptr"][-1] == g.E
+    assert sorted(ex["transpose"].tolist()) == list(range(g.E))
+
+
+def test_all_zero_codeword_all_rules(O, peg):
+    llr = np.full((2, 1008), 2.0, np.float32)
+    for rule in O.RULES:
+        for sched in O.SCHEDULES:
+            r = O.decode(peg, llr, rule, 0.75 if rule == "NMS" else 0.0, 5, sched)
+            assert (r["hard"] == 0).all() and (r["iters"] == 1).all()
+
+
+def test_threads_do_not_change_results(O, peg):
+    rng = np.random.default_rng(3)
+    llr = np.where(rng.random((16, 1008)) < 0.07, -2.59, 2.59).astype(np.float32)
+    a = O.decode(peg, llr, "NMS", 0.75, 20, n_threads=1)
+    b = O.decode(peg, llr, "NMS", 0.75, 20, n_threads=4)
+    assert (a["hard"] == b["hard"]).all() and (a["iters"] == b["iters"]).all() and (a["post"] == b["post"]).all()

@@ -1,0 +1,289 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: MS/OMS/NMS (and the AMS<min> member) fp32 -- identical hard decisions,
+iteration counts, success flags AND posteriors (bit-exact floats) on every frame.  SPA / LSPA / min*:
+identical on the reference's known-answer vector; on random frames >= 99 % identical frame verdicts
+(device tanh/atanh/log/exp differ from glibc in the last ulp).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EXACT = [("MS", 0.0), ("OMS", 0.35), ("NMS", 0.75), ("AMS_MIN", 0.0)]
+SOFT = [("SPA", 0.0), ("LSPA", 0.0), ("AMS_MINSTAR", 0.0), ("AMS_MINSTAR_L2", 0.0)]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def kat(gold):
+    return json.load(open(os.path.join(gold, "kat_peg504x1008.json")))
+
+
+@pytest.fixture(scope="module")
+def peg(q, O, gold):
+    p = os.path.join(gold, "PEGReg504x1008.alist")
+    return q.Code.from_alist(p), O.Graph.from_alist(p)
+
+
+def bsc_frames(rng, F, N, p, mag):
+    return np.where(rng.random((F, N)) < p, -mag, mag).astype(np.float32)
+
+
+def staged(q, torch, dec, llr, want_post=True):
+    t = torch.from_numpy(llr).cuda()
+    dec.load_llr(t)
+    dec.run()
+    hard = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), dec.N)
+    it, ok = dec.fetch_status()
+    post = dec.fetch_post().cpu().numpy() if want_post else None
+    return hard, it.cpu().numpy(), ok.cpu().numpy(), post
+
+
+def test_kat_through_the_c_abi(q, peg, kat):
+    code, _ = peg
+    dec = q.Decoder(code, 504, 10, info_bits_pos=np.arange(504, 1008), rule="SPA", n_frames=1)
+    V = dec.decode_siho(np.array(kat["llrs"], np.float32))
+    assert (V[0] == np.array(kat["decoded"])).all()
+    dec.reset()
+    V2 = dec.decode_siho(np.array(kat["llrs"], np.float32))     # reset() -> same answer again (BS/src/main.cpp:389)
+    assert (V2 == V).all()
+
+
+@pytest.mark.parametrize("sched", ["flooding", "hlayered"])
+@pytest.mark.parametrize("rule,param", EXACT)
+@pytest.mark.parametrize("V", [1, 2, 4])
+def test_minsum_family_bit_exact(q, O, torch, peg, rule, param, sched, V):
+    code, og = peg
+    F = 300                                                     # ragged: not a multiple of 64*V
+    llr = bsc_frames(np.random.default_rng(10 + V), F, 1008, 0.065, 2.6)
+    if sched == "hlayered":
+        order, _, _ = code.layer_order()
+        var, chk = og.edges()
+        inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+        og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    ref = O.decode(og, llr, rule, param, 25, sched, True, 1, n_threads=8)
+    dec = q.Decoder(code, 1008, 25, rule=rule, rule_param=param, n_frames=F, schedule=sched, frames_per_lane=V)
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all()
+    assert (it == ref["iters"]).all()
+    assert (ok == ref["synd_ok"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()     # bit-exact floats
+    assert 0 < (ref["synd_ok"] == 0).sum() < F                              # both outcomes are exercised
+
+
+def _reorder(var, chk, inv):
+    """edge list of the row-permuted H: check c becomes inv[c]; keeps each check's edge order"""
+    newc = inv[chk]
+    idx = np.argsort(newc, kind="stable")
+    return var[idx], newc[idx]
+
+
+@pytest.mark.parametrize("rule,param", EXACT[:3])
+def test_fixed_iterations_no_syndrome(q, O, torch, peg, rule, param):
+    code, og = peg
+    llr = bsc_frames(np.random.default_rng(5), 130, 1008, 0.06, 2.75)
+    ref = O.decode(og, llr, rule, param, 12, "flooding", False, 1, n_threads=8)
+    dec = q.Decoder(code, 1008, 12, rule=rule, rule_param=param, n_frames=130, enable_syndrome=False)
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == 12).all() and (ok == ref["synd_ok"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_syndrome_depth(q, O, torch, peg, depth):
+    code, og = peg
+    llr = bsc_frames(np.random.default_rng(6), 64, 1008, 0.05, 2.9)
+    ref = O.decode(og, llr, "NMS", 0.75, 30, "flooding", True, depth, n_threads=8)
+    dec = q.Decoder(code, 1008, 30, rule="NMS", rule_param=0.75, n_frames=64, syndrome_depth=depth)
+    hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
+
+
+@pytest.mark.parametrize("sched", ["flooding", "hlayered"])
+@pytest.mark.parametrize("rule,param", SOFT)
+def test_transcendental_rules_tolerance(q, O, torch, peg, rule, param, sched):
+    code, og = peg
+    if sched == "hlayered":
+        order, _, _ = code.layer_order()
+        var, chk = og.edges()
+        inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+        og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    F = 256
+    llr = bsc_frames(np.random.default_rng(7), F, 1008, 0.07, 2.59)
+    ref = O.decode(og, llr, rule, param, 20, sched, True, 1, n_threads=8)
+    dec = q.Decoder(code, 1008, 20, rule=rule, rule_param=param, n_frames=F, schedule=sched)
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    same = (hard == ref["hard"]).all(axis=1)
+    assert same.mean() >= 0.99, same.mean()                     # tolerance: >= 99 % identical frame verdicts
+    assert (ok == ref["synd_ok"]).mean() >= 0.99
+    conv = (ref["synd_ok"] == 1) & (ok == 1)
+    assert np.abs(it[conv] - ref["iters"][conv]).max() <= 1
+    good = same & conv & (it == ref["iters"])
+    rel = np.abs(post[good] - ref["post"][good]) / (1.0 + np.abs(ref["post"][good]))
+    assert rel.max() < 2e-3                                     # tolerance on posteriors: 2e-3 relative
+
+
+@pytest.mark.parametrize("F", [1, 63, 64, 65, 129])
+def test_ragged_batches(q, O, torch, peg, F):
+    code, og = peg
+    llr = bsc_frames(np.random.default_rng(F), F, 1008, 0.06, 2.75)
+    ref = O.decode(og, llr, "NMS", 0.8, 20, n_threads=8)
+    dec = q.Decoder(code, 1008, 20, rule="NMS", rule_param=0.8, n_frames=max(F, 70))     # capacity > load
+    hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
+    assert hard.shape == (F, 1008) and (hard == ref["hard"]).all() and (it == ref["iters"]).all()
+
+
+def test_load_more_than_capacity_is_an_error(q, torch, peg):
+    code, _ = peg
+    dec = q.Decoder(code, 1008, 5, rule="MS", n_frames=8)
+    with pytest.raises(q.QldpcError) as e:
+        dec.load_llr(torch.zeros((9, 1008), device="cuda"))
+    assert e.value.status == -6
+    with pytest.raises(q.QldpcError) as e:
+        dec.run()
+    assert e.value.status == -8
+
+
+def test_qkd_frame_formation_from_packed_bits(q, O, torch, peg, kat):
+    """BS/src/main.cpp:348-362: channel bits -> +-ln((1-p)/p), parity VNs pinned +-23.03, punctured -> 0."""
+    code, og = peg
+    rng = np.random.default_rng(11)
+    F, N = 70, 1008
+    enc = q.Encoder(code, "IDENTITY")
+    cw = enc.encode(rng.integers(0, 2, (F, enc.K)))
+    qber = rng.uniform(0.02, 0.05, F).astype(np.float32)
+    noisy = cw ^ (rng.random((F, N)) < qber[:, None])
+    cls = np.zeros(N, np.uint8)
+    par = np.setdiff1d(np.arange(N), enc.info_bits_pos)
+    cls[par] = q.VN_PINNED
+    cls[par[:40]] = q.VN_PUNCTURED
+    noisy[:, par] = cw[:, par]                                   # Alice discloses the parity bits
+    mag = np.array([q.bsc_llr(p) for p in qber], np.float32)
+    llr = np.where(noisy == 1, -mag[:, None], mag[:, None]).astype(np.float32)
+    llr[:, par] = np.where(cw[:, par] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
+    llr[:, par[:40]] = 0.0
+    ref = O.decode(og, llr, "NMS", 0.75, 30, n_threads=8)
+    dec = q.Decoder(code, enc.K, 30, info_bits_pos=enc.info_bits_pos, rule="NMS", rule_param=0.75, n_frames=F)
+    bits = torch.from_numpy(q.pack_bits(noisy).astype(np.int64).astype(np.uint32).view(np.int32)).cuda()
+    dec.load_bits(bits, torch.from_numpy(mag).cuda(), torch.from_numpy(cls).cuda())
+    dec.run()
+    hard = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), N)
+    assert (hard == ref["hard"]).all()
+    info = dec.fetch_info().cpu().numpy()
+    assert (info == ref["hard"][:, enc.info_bits_pos]).all()
+    assert (dec.fetch_post().cpu().numpy().view(np.uint32) == ref["post"].view(np.uint32)).all()
+    okf = ref["synd_ok"] == 1
+    assert okf.mean() > 0.8 and (hard[okf] == cw[okf]).all()    # decoded word == Alice's codeword
+
+
+def test_encoder_identity_matches_kat(q, peg, kat):
+    """Encoder_LDPC_from_H(..., "IDENTITY", ...) pin: VAR/main.cpp (alist-v1.0.1):445,447."""
+    code, _ = peg
+    enc = q.Encoder(code, "IDENTITY")
+    assert enc.K == 504 and (enc.info_bits_pos == np.arange(504, 1008)).all()
+    X = enc.encode(np.array(kat["data"]))
+    assert (X[0] == np.array(kat["encoded"])).all()
+
+
+def test_encoder_ira_and_roundtrip_full_size(q, O, torch):
+    """config 2 code at full size: encode -> BSC 2 % -> decode == codeword; 64 frames vs the oracle."""
+    code = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
+    enc = q.Encoder(code, "IRA")
+    rng = np.random.default_rng(21)
+    F = 64
+    cw = enc.encode(rng.integers(0, 2, (F, enc.K)))
+    for f in range(0, F, 16):
+        assert code.syndrome(cw[f])[0] == 0
+    mag = np.float32(q.bsc_llr(0.02))
+    noisy = cw.copy()
+    noisy[:, :enc.K] ^= rng.random((F, enc.K)) < 0.02
+    llr = np.where(noisy == 1, -mag, mag).astype(np.float32)
+    llr[:, enc.K:] = np.where(cw[:, enc.K:] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    ref = O.decode(og, llr, "NMS", 0.75, 50, n_threads=8)
+    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, n_frames=F)
+    hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    assert (ok == 1).all() and (hard == cw).all()
+    assert 5 <= it.mean() <= 20
+
+
+@pytest.mark.parametrize("name,kind", [("NR_2_3_112.qc", "qc"), ("20.alist", "alist"), ("1998.5.3.2665.alist", "alist")])
+def test_other_matrices(q, O, torch, gold, name, kind):
+    p = os.path.join(gold, name)
+    code = q.Code.from_qc(p) if kind == "qc" else q.Code.from_alist(p)
+    og = O.Graph.from_qc(p) if kind == "qc" else O.Graph.from_alist(p)
+    llr = bsc_frames(np.random.default_rng(3), 96, code.N, 0.03, 3.4)
+    for sched in ("flooding", "hlayered"):
+        g2 = og
+        if sched == "hlayered":
+            order, _, _ = code.layer_order()
+            var, chk = og.edges()
+            inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+            g2 = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+        ref = O.decode(g2, llr, "OMS", 0.3, 15, sched, n_threads=8)
+        dec = q.Decoder(code, code.N, 15, rule="OMS", rule_param=0.3, n_frames=96, schedule=sched)
+        hard, it, ok, post = staged(q, torch, dec, llr)
+        assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
+        assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
+def test_natural_layer_order_equals_plain_sequential_sweep(q, O, torch, gold):
+    """For a QC code the level schedule must equal AFF3CT's c = 0..M-1 sweep on the UNpermuted H."""
+    p = os.path.join(gold, "NR_2_3_112.qc")
+    code, og = q.Code.from_qc(p), O.Graph.from_qc(p)
+    assert code.layer_order()[2]
+    llr = bsc_frames(np.random.default_rng(4), 64, code.N, 0.04, 3.1)
+    ref = O.decode(og, llr, "NMS", 0.8, 10, "hlayered", n_threads=8)
+    dec = q.Decoder(code, code.N, 10, rule="NMS", rule_param=0.8, n_frames=64, schedule="hlayered")
+    hard, it, _, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
+def test_high_degree_checks_use_the_generic_kernel(q, O, torch):
+    code = q.Code.ira(4096, 3850, 0.4, 14, 4, 3)               # rate 0.94 -> check degree > 40
+    assert code.max_cn_degree > 40
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    llr = bsc_frames(np.random.default_rng(8), 64, code.N, 0.004, 5.5)
+    ref = O.decode(og, llr, "NMS", 0.75, 12, n_threads=8)
+    dec = q.Decoder(code, code.N, 12, rule="NMS", rule_param=0.75, n_frames=64)
+    hard, it, _, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
+def test_zero_llr_and_all_converged_inputs(q, O, torch, peg):
+    code, og = peg
+    llr = np.zeros((3, 1008), np.float32)                       # everything erased: stays at 0, never "fails" to parse
+    llr[1] = 4.0                                                # trivially converged frame
+    llr[2, ::2] = -4.0
+    ref = O.decode(og, llr, "MS", 0.0, 8, n_threads=1)
+    dec = q.Decoder(code, 1008, 8, rule="MS", n_frames=3)
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
+def test_profile_hooks_report_algorithmic_bytes(q, torch, peg):
+    code, _ = peg
+    dec = q.Decoder(code, 1008, 6, rule="NMS", rule_param=0.75, n_frames=128, enable_syndrome=False)
+    dec.profile(True)
+    dec.load_llr(torch.from_numpy(bsc_frames(np.random.default_rng(2), 128, 1008, 0.05, 2.9)).cuda())
+    dec.run()
+    st = {s["name"]: s for s in dec.profile_read()}
+    assert st["cn_update"]["launches"] == 6 and st["vn_update"]["launches"] == 7       # FIRST + 5 + POST
+    assert st["cn_update"]["alg_bytes"] == 6 * 2 * 3024 * 4 * 128
+    assert st["cn_update"]["total_ms"] > 0
