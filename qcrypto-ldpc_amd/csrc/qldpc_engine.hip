@@ -158,8 +158,10 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
 
     int rc;
     if ((rc = dev_alloc(d, &d->d_cn_ptr, (size_t)d->M + 1))) return rc;
-    if ((rc = dev_alloc(d, &d->d_cn_tr, (size_t)d->E))) return rc;
-    if ((rc = dev_alloc(d, &d->d_cn_var, (size_t)d->E))) return rc;
+    if ((rc = dev_alloc(d, &d->d_cn_tr, (size_t)d->E + QK_IDX_PAD))) return rc;
+    if ((rc = dev_alloc(d, &d->d_cn_var, (size_t)d->E + QK_IDX_PAD))) return rc;
+    HIPCHK(hipMemset(d->d_cn_tr, 0, sizeof(int) * ((size_t)d->E + QK_IDX_PAD)));
+    HIPCHK(hipMemset(d->d_cn_var, 0, sizeof(int) * ((size_t)d->E + QK_IDX_PAD)));
     if ((rc = dev_alloc(d, &d->d_vn_ptr, (size_t)d->N + 1))) return rc;
     if ((rc = dev_alloc(d, &d->d_info_pos, (size_t)K))) return rc;
     HIPCHK(hipMemcpy(d->d_cn_ptr, code->cn_ptr, sizeof(int) * ((size_t)d->M + 1), hipMemcpyHostToDevice));
@@ -307,13 +309,10 @@ extern "C" int qldpc_profile_clear(qldpc_decoder *d)
         if (e__ != hipSuccess) { qldpc_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); return QLDPC_EHIP; } \
     } while (0)
 
-static inline int grid_x(const qldpc_decoder *d, int n_items)
+static inline int grid_x(int n_items, int per_wave)
 {
-    const int per_block = QK_WAVES;
-    int want = (n_items + per_block - 1) / per_block;
-    int cap = 8192 / std::max(1, d->G);
-    if (cap < 1) cap = 1;
-    return std::max(1, std::min(want, cap));
+    const int per_block = QK_WAVES * per_wave;
+    return std::max(1, (n_items + per_block - 1) / per_block);
 }
 
 static int family_of(int rule)
@@ -329,7 +328,7 @@ static int family_of(int rule)
 template <int V, int CAP, int FAM>
 static void launch_cn_one(qldpc_decoder *d, const bucket &b)
 {
-    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
+    dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_tr,
                        (size_t)d->E * d->FG, d->d_done, r);
@@ -359,7 +358,7 @@ static void launch_cn(qldpc_decoder *d, const bucket &b)
 template <int V, int CAP, int FAM>
 static void launch_layer_one(qldpc_decoder *d, const bucket &b)
 {
-    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
+    dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
                        d->N, (size_t)d->E * d->FG, d->d_done, r);
@@ -389,8 +388,9 @@ static void launch_layer(qldpc_decoder *d, const bucket &b)
 template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
 {
-    dim3 grid((unsigned)grid_x(d, b.n), (unsigned)d->G);
-    hipLaunchKernelGGL((qk_vn_flood<V, CAP, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
+    constexpr int UN = (CAP > 0 && CAP <= 4) ? 4 : (CAP > 0 ? 2 : 2);
+    dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
+    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
                        b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
 }
 template <int V, int MODE>

@@ -23,6 +23,7 @@ typedef unsigned long long u64;
 
 #define QK_WAVES 4            /* wavefronts per workgroup */
 #define QK_THREADS (QK_WAVES * 64)
+#define QK_IDX_PAD 64         /* ints of padding after cn_tr / cn_var so unconditional index reads stay in bounds */
 
 /* rule families (template parameter); the member of the family is a wave-uniform runtime value */
 #define QK_FAM_MS 0           /* MS / OMS / NMS                 */
@@ -188,7 +189,10 @@ template <int V> __device__ __forceinline__ bool qk_frozen(const u64 *__restrict
 
 /*
  * _decode_single_ite of Decoder_LDPC_BP_flooding: for each check gather var_to_chk through
- * `transpose`, fold, emit chk_to_var to the same slots.  One wavefront per check, FG frames wide.
+ * `transpose`, fold, emit chk_to_var to the same slots.  ONE wavefront per check, FG frames wide,
+ * one check per wavefront per launch: all graph indices are fetched with back-to-back scalar loads
+ * (cn_tr is padded by QK_IDX_PAD ints so the reads past `deg` stay in bounds), then every message
+ * row load is in flight before the first use; the hardware overlaps checks across wavefronts.
  * DCMAX > 0: messages stay in registers (checks in `list` have degree <= DCMAX).
  * DCMAX == 0: any degree, second pass re-reads the rows (they are L2-hot).
  */
@@ -203,56 +207,69 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
     if (qk_group_done<V>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * QK_WAVES + wave;
+    if (i >= n_list) return;
     bool frozen[V];
     const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
     const float *vin = v2c + (size_t)g * group_stride + lane * V;
     float *cout = c2v + (size_t)g * group_stride + lane * V;
 
-    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
-        const int c = list[i];
-        const int b = cn_ptr[c];
-        const int deg = cn_ptr[c + 1] - b;
-        qk_acc<FAM> acc[V];
+    const int c = list[i];
+    const int b = cn_ptr[c];
+    const int deg = cn_ptr[c + 1] - b;
+    qk_acc<FAM> acc[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[j].begin();
-        if constexpr (DCMAX > 0) {
-            float x[DCMAX][V];
+    for (int j = 0; j < V; j++) acc[j].begin();
+    if constexpr (DCMAX > 0) {
+        int slot[DCMAX];
 #pragma unroll
-            for (int k = 0; k < DCMAX; k++)
-                if (k < deg) qk_load<V>(x[k], vin + (size_t)cn_tr[b + k] * FG);
+        for (int k = 0; k < DCMAX; k++) slot[k] = cn_tr[b + k];
+        float x[DCMAX][V];
 #pragma unroll
-            for (int k = 0; k < DCMAX; k++)
-                if (k < deg) {
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) qk_load<V>(x[k], vin + (size_t)slot[k] * FG);
 #pragma unroll
-                    for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
-                }
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
 #pragma unroll
-            for (int j = 0; j < V; j++) acc[j].finish(rule);
+                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
+            }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].finish(rule);
+        if (!any_frozen) {
 #pragma unroll
             for (int k = 0; k < DCMAX; k++)
                 if (k < deg) {
                     float o[V];
 #pragma unroll
                     for (int j = 0; j < V; j++) o[j] = acc[j].out(x[k][j], rule);
-                    qk_store_masked<V>(cout + (size_t)cn_tr[b + k] * FG, o, frozen, any_frozen);
+                    qk_store<V>(cout + (size_t)slot[k] * FG, o);
                 }
         } else {
-            for (int k = 0; k < deg; k++) {
-                float x[V];
-                qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
 #pragma unroll
-                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[j], rule);
-            }
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
 #pragma unroll
-            for (int j = 0; j < V; j++) acc[j].finish(rule);
-            for (int k = 0; k < deg; k++) {
-                float x[V], o[V];
-                const size_t off = (size_t)cn_tr[b + k] * FG;
-                qk_load<V>(x, vin + off);
+                    for (int j = 0; j < V; j++)
+                        if (!frozen[j]) cout[(size_t)slot[k] * FG + j] = acc[j].out(x[k][j], rule);
+                }
+        }
+    } else {
+        for (int k = 0; k < deg; k++) {
+            float x[V];
+            qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
 #pragma unroll
-                for (int j = 0; j < V; j++) o[j] = acc[j].out(x[j], rule);
-                qk_store_masked<V>(cout + off, o, frozen, any_frozen);
-            }
+            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[j], rule);
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].finish(rule);
+        for (int k = 0; k < deg; k++) {
+            float x[V], o[V];
+            const size_t off = (size_t)cn_tr[b + k] * FG;
+            qk_load<V>(x, vin + off);
+#pragma unroll
+            for (int j = 0; j < V; j++) o[j] = acc[j].out(x[j], rule);
+            qk_store_masked<V>(cout + off, o, frozen, any_frozen);
         }
     }
 }
@@ -268,8 +285,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
  * tmp = Y[v] + sum; var_to_chk[slot] = tmp - chk_to_var[slot].  A VN's slots are contiguous rows,
  * so this kernel streams.  Also emits the per-VN ballots: sgn = signbit(tmp) (what
  * check_syndrome_soft tests) and hard = !(tmp >= 0) (what decode_siho outputs).
+ * One wavefront handles UN list entries with every row load issued before the first use.
  */
-template <int V, int DVMAX, int MODE>
+template <int V, int DVMAX, int UN, int MODE>
 __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restrict__ c2v, const float *__restrict__ llr,
                                                           float *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
                                                           float *__restrict__ post_out,
@@ -285,75 +303,99 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restric
     const float *cin = c2v + (size_t)g * group_stride + lane * V;
     float *vout = v2c + (size_t)g * group_stride + lane * V;
     const float *yin = llr + (size_t)g * N * FG + lane * V;
+    const int i0 = (blockIdx.x * QK_WAVES + wave) * UN;
+    if (i0 >= n_list) return;
 
-    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
-        const int v = list[i];
-        const int b = vn_ptr[v];
-        const int deg = vn_ptr[v + 1] - b;
-        float y[V], sum[V], tmp[V];
-        qk_load<V>(y, yin + (size_t)v * FG);
+    int vv[UN], bb[UN], dd[UN];
 #pragma unroll
-        for (int j = 0; j < V; j++) sum[j] = 0.0f;
-        if constexpr (MODE == QK_VN_FIRST) {
+    for (int u = 0; u < UN; u++) {
+        const int i = (i0 + u < n_list) ? i0 + u : i0;      /* the tail repeats entry i0 (idempotent) */
+        vv[u] = list[i];
+    }
 #pragma unroll
-            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+    for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
+    float y[UN][V], tmp[UN][V];
+#pragma unroll
+    for (int u = 0; u < UN; u++) qk_load<V>(y[u], yin + (size_t)vv[u] * FG);
+
+    if constexpr (MODE == QK_VN_FIRST) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
             float o[V];
 #pragma unroll
-            for (int j = 0; j < V; j++) o[j] = tmp[j] - 0.0f;
-            for (int k = 0; k < deg; k++) qk_store<V>(vout + (size_t)(b + k) * FG, o);
-        } else if constexpr (DVMAX > 0) {
-            float m[DVMAX][V];
+            for (int j = 0; j < V; j++) { tmp[u][j] = y[u][j] + 0.0f; o[j] = tmp[u][j] - 0.0f; }
+            for (int k = 0; k < dd[u]; k++) qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
+        }
+    } else if constexpr (DVMAX > 0) {
+        float m[UN][DVMAX][V];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
 #pragma unroll
             for (int k = 0; k < DVMAX; k++)
-                if (k < deg) qk_load<V>(m[k], cin + (size_t)(b + k) * FG);
+                if (k < dd[u]) qk_load<V>(m[u][k], cin + (size_t)(bb[u] + k) * FG);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            float sum[V];
+#pragma unroll
+            for (int j = 0; j < V; j++) sum[j] = 0.0f;
 #pragma unroll
             for (int k = 0; k < DVMAX; k++)
-                if (k < deg) {
+                if (k < dd[u]) {
 #pragma unroll
-                    for (int j = 0; j < V; j++) sum[j] += m[k][j];
+                    for (int j = 0; j < V; j++) sum[j] += m[u][k][j];
                 }
 #pragma unroll
-            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+            for (int j = 0; j < V; j++) tmp[u][j] = y[u][j] + sum[j];
             if constexpr (MODE == QK_VN_NORMAL) {
 #pragma unroll
                 for (int k = 0; k < DVMAX; k++)
-                    if (k < deg) {
+                    if (k < dd[u]) {
                         float o[V];
 #pragma unroll
-                        for (int j = 0; j < V; j++) o[j] = tmp[j] - m[k][j];
-                        qk_store<V>(vout + (size_t)(b + k) * FG, o);
+                        for (int j = 0; j < V; j++) o[j] = tmp[u][j] - m[u][k][j];
+                        qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
                     }
             }
-        } else {
-            for (int k = 0; k < deg; k++) {
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            float sum[V];
+#pragma unroll
+            for (int j = 0; j < V; j++) sum[j] = 0.0f;
+            for (int k = 0; k < dd[u]; k++) {
                 float m[V];
-                qk_load<V>(m, cin + (size_t)(b + k) * FG);
+                qk_load<V>(m, cin + (size_t)(bb[u] + k) * FG);
 #pragma unroll
                 for (int j = 0; j < V; j++) sum[j] += m[j];
             }
 #pragma unroll
-            for (int j = 0; j < V; j++) tmp[j] = y[j] + sum[j];
+            for (int j = 0; j < V; j++) tmp[u][j] = y[u][j] + sum[j];
             if constexpr (MODE == QK_VN_NORMAL) {
-                for (int k = 0; k < deg; k++) {
+                for (int k = 0; k < dd[u]; k++) {
                     float m[V], o[V];
-                    qk_load<V>(m, cin + (size_t)(b + k) * FG);
+                    qk_load<V>(m, cin + (size_t)(bb[u] + k) * FG);
 #pragma unroll
-                    for (int j = 0; j < V; j++) o[j] = tmp[j] - m[j];
-                    qk_store<V>(vout + (size_t)(b + k) * FG, o);
+                    for (int j = 0; j < V; j++) o[j] = tmp[u][j] - m[j];
+                    qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
                 }
             }
         }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-            const u64 s = __ballot((qk_bits(tmp[j]) >> 31) != 0);
-            if (lane == 0) sgn[((size_t)g * N + v) * V + j] = s;
+            const u64 s = __ballot((qk_bits(tmp[u][j]) >> 31) != 0);
+            if (lane == 0) sgn[((size_t)g * N + vv[u]) * V + j] = s;
             if constexpr (MODE == QK_VN_POST) {
-                const u64 h = __ballot(!(tmp[j] >= 0.0f));
-                if (lane == 0) hard[((size_t)g * N + v) * V + j] = h;
+                const u64 h = __ballot(!(tmp[u][j] >= 0.0f));
+                if (lane == 0) hard[((size_t)g * N + vv[u]) * V + j] = h;
             }
         }
         if constexpr (MODE == QK_VN_POST) {
-            if (post_out) qk_store<V>(post_out + ((size_t)g * N + v) * FG + lane * V, tmp);
+            if (post_out) qk_store<V>(post_out + ((size_t)g * N + vv[u]) * FG + lane * V, tmp[u]);
         }
     }
 }
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restric
  * One layer (VN-disjoint checks) of Decoder_LDPC_BP_horizontal_layered::_decode_single_ite:
  *   contributions[i] = var_nodes[v_i] - messages[k]; fold; messages[k] = out_i;
  *   var_nodes[v_i] = contributions[i] + messages[k]
- * msg is CN-major [G][E][FG]; post is [G][N][FG].
+ * msg is CN-major [G][E][FG]; post is [G][N][FG].  One wavefront per check.
  */
 template <int V, int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ post, float *__restrict__ msg,
@@ -377,65 +419,65 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
     if (qk_group_done<V>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * QK_WAVES + wave;
+    if (i >= n_list) return;
     bool frozen[V];
     const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
     float *pg = post + (size_t)g * N * FG + lane * V;
     float *mg = msg + (size_t)g * group_stride + lane * V;
 
-    for (int i = blockIdx.x * QK_WAVES + wave; i < n_list; i += gridDim.x * QK_WAVES) {
-        const int c = list[i];
-        const int b = cn_ptr[c];
-        const int deg = cn_ptr[c + 1] - b;
-        qk_acc<FAM> acc[V];
+    const int c = list[i];
+    const int b = cn_ptr[c];
+    const int deg = cn_ptr[c + 1] - b;
+    qk_acc<FAM> acc[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[j].begin();
-        if constexpr (DCMAX > 0) {
-            float x[DCMAX][V];
+    for (int j = 0; j < V; j++) acc[j].begin();
+    if constexpr (DCMAX > 0) {
+        int vn[DCMAX];
 #pragma unroll
-            for (int k = 0; k < DCMAX; k++)
-                if (k < deg) {
-                    float p[V], m[V];
-                    qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
-                    qk_load<V>(m, mg + (size_t)(b + k) * FG);
+        for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+        float x[DCMAX][V], m[DCMAX][V];
 #pragma unroll
-                    for (int j = 0; j < V; j++) x[k][j] = p[j] - m[j];
-                }
-#pragma unroll
-            for (int k = 0; k < DCMAX; k++)
-                if (k < deg) {
-#pragma unroll
-                    for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
-                }
-#pragma unroll
-            for (int j = 0; j < V; j++) acc[j].finish(rule);
-#pragma unroll
-            for (int k = 0; k < DCMAX; k++)
-                if (k < deg) {
-                    float o[V], p[V];
-#pragma unroll
-                    for (int j = 0; j < V; j++) { o[j] = acc[j].out(x[k][j], rule); p[j] = x[k][j] + o[j]; }
-                    qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
-                    qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
-                }
-        } else {
-            for (int k = 0; k < deg; k++) {
-                float p[V], m[V];
-                qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
-                qk_load<V>(m, mg + (size_t)(b + k) * FG);
-#pragma unroll
-                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], p[j] - m[j], rule);
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
+                qk_load<V>(x[k], pg + (size_t)vn[k] * FG);
+                qk_load<V>(m[k], mg + (size_t)(b + k) * FG);
             }
 #pragma unroll
-            for (int j = 0; j < V; j++) acc[j].finish(rule);
-            for (int k = 0; k < deg; k++) {
-                float p[V], m[V], o[V];
-                qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
-                qk_load<V>(m, mg + (size_t)(b + k) * FG);
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
 #pragma unroll
-                for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(x, rule); p[j] = x + o[j]; }
+                for (int j = 0; j < V; j++) { x[k][j] = x[k][j] - m[k][j]; qk_acc_in<FAM>(acc[j], x[k][j], rule); }
+            }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].finish(rule);
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
+                float o[V], p[V];
+#pragma unroll
+                for (int j = 0; j < V; j++) { o[j] = acc[j].out(x[k][j], rule); p[j] = x[k][j] + o[j]; }
                 qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
-                qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
+                qk_store_masked<V>(pg + (size_t)vn[k] * FG, p, frozen, any_frozen);
             }
+    } else {
+        for (int k = 0; k < deg; k++) {
+            float p[V], m[V];
+            qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
+            qk_load<V>(m, mg + (size_t)(b + k) * FG);
+#pragma unroll
+            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], p[j] - m[j], rule);
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j].finish(rule);
+        for (int k = 0; k < deg; k++) {
+            float p[V], m[V], o[V];
+            qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
+            qk_load<V>(m, mg + (size_t)(b + k) * FG);
+#pragma unroll
+            for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(x, rule); p[j] = x + o[j]; }
+            qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
+            qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
         }
     }
 }
