@@ -49,7 +49,8 @@ typedef enum qldpc_status {
     QLDPC_ENODEV = -5,       /* no gfx950-capable device visible                                */
     QLDPC_ESIZE = -6,        /* size mismatch (AFF3CT throws tools::length_error here)          */
     QLDPC_EUNSUPPORTED = -7, /* valid request this build does not implement                     */
-    QLDPC_ESTATE = -8        /* call sequence error (e.g. run before load)                      */
+    QLDPC_ESTATE = -8,       /* call sequence error (e.g. run before load)                      */
+    QLDPC_EDECODE = -9       /* reconciliation failed: no codeword found or CRC mismatch        */
 } qldpc_status;
 
 /* tools::Update_rule_* selected at VAR/main.cpp (alist-v1.0.1):203-218 */
@@ -200,6 +201,63 @@ int qldpc_encode(qldpc_encoder *enc, const int *U_K, int *X_N, int n_frames);
 /* device, packed MSB-first: d_info[n_frames][ceil(K/32)] -> d_cw[n_frames][ceil(N/32)]. */
 int qldpc_encode_packed_dev(qldpc_encoder *enc, const uint32_t *d_info, uint32_t *d_cw, int n_frames,
                             void *hip_stream);
+
+/* ------------------------------------------------------------------ reconciliation sessions -- */
+/*
+ * What an ecd2 LDPC handler does between QBER estimation and privacy amplification, i.e. the
+ * replacement of the cascade_biconf exchange (subcomponents/cascade_biconf.c:427-940, ~55 packets
+ * each way) by ONE parity message: the two `return 81` arms at subcomponents/qber_estim.c:337-340
+ * and :420-423 call into this.  Buffers are the daemon's own: ProcessBlock.mainBufPtr words,
+ * MSB-first (helpers.h:65-70), `workbits` valid bits (helpers.c:31-69), QBER = localError.
+ *
+ * Per block: rate = largest table rate <= min_cr(qber, efficiency) (BS/src/main.cpp:29,235-266);
+ * code = IRA with K = workbits rounded up to `key_quantum` (extra info VNs are shortened: known 0)
+ * and M = round(K (1-R)/R) parity VNs; Alice sends the M parity bits + CRC-32 of her key; Bob pins
+ * them (+-23.03), decodes and verifies.  Leak = M + 32 bits.
+ */
+typedef struct qldpc_recon qldpc_recon;
+
+typedef struct qldpc_recon_cfg {
+    int device;
+    float efficiency;      /* f in min_cr(q, f); 1.4                        */
+    int n_rates;           /* <= 8                                                               */
+    float rates[8];        /* ascending; default {0.5, 0.7, 0.8, 0.9}                            */
+    int n_ite;             /* 50                                                                 */
+    int rule;              /* QLDPC_RULE_NMS                                                     */
+    float rule_param;      /* 0.75                                                               */
+    int key_quantum;       /* 1024 (multiple of 32)                                              */
+    int max_blocks;        /* blocks decoded concurrently by qldpc_recon_decode_batch            */
+    uint64_t seed;         /* IRA construction seed shared by both sides (7)                     */
+    int reserved[8];
+} qldpc_recon_cfg;
+
+/* Travels in the parity packet (all fields uint32, little-endian like every ecd2 header). */
+typedef struct qldpc_recon_msg {
+    uint32_t rate_index;   /* index into the rate table                                          */
+    uint32_t key_bits;     /* workbits                                                           */
+    uint32_t code_k;       /* info VNs (key_bits rounded up to key_quantum)                      */
+    uint32_t code_m;       /* parity VNs = disclosed bits                                        */
+    uint32_t crc32;        /* CRC-32 (IEEE) of Alice's key words, tail bits masked               */
+} qldpc_recon_msg;
+
+void qldpc_recon_cfg_default(qldpc_recon_cfg *cfg);
+int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out);
+void qldpc_recon_free(qldpc_recon *r);
+/* Rate choice and code dimensions for a block; fills rate_index, key_bits, code_k, code_m. */
+int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon_msg *msg);
+/* Alice: parity words (ceil(code_m/32), MSB-first) + message header for her key. */
+int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber,
+                       qldpc_recon_msg *msg_out, uint32_t *parity_words, int parity_cap_words);
+/* Bob: corrects key_words in place.  QLDPC_OK = decoded and CRC verified; QLDPC_EDECODE = failed,
+ * key untouched.  corrected_bits / leaked_bits / iterations may be NULL. */
+int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float qber, const qldpc_recon_msg *msg,
+                       const uint32_t *parity_words, int *corrected_bits, int *leaked_bits, int *iterations);
+/* Bob, n blocks that share one plan (same key_bits / rate / code dims) in one launch.
+ * key_words[n][ceil(key_bits/32)], parity_words[n][ceil(code_m/32)], status[n] = QLDPC_OK / QLDPC_EDECODE. */
+int qldpc_recon_decode_batch(qldpc_recon *r, int n_blocks, uint32_t *key_words, int key_bits, const float *qber,
+                             const qldpc_recon_msg *msgs, const uint32_t *parity_words, int *status,
+                             int *corrected_bits, int *iterations);
+uint32_t qldpc_crc32_words(const uint32_t *words, int n_bits);
 
 #ifdef __cplusplus
 }

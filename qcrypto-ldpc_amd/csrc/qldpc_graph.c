@@ -46,6 +46,7 @@ const char *qldpc_strerror(int status)
     case QLDPC_ESIZE: return "size mismatch";
     case QLDPC_EUNSUPPORTED: return "unsupported";
     case QLDPC_ESTATE: return "call sequence error";
+    case QLDPC_EDECODE: return "reconciliation failed";
     default: return "unknown status";
     }
 }
