@@ -412,3 +412,93 @@ def unpack_bits(words, n):
     by = np.stack([(w >> 24) & 255, (w >> 16) & 255, (w >> 8) & 255, w & 255], axis=-1).astype(np.uint8)
     bits = np.unpackbits(by.reshape(w.shape[:-1] + (-1,)), axis=-1, bitorder="big")
     return bits[..., :n]
+
+
+# ---- reconciliation sessions (engine of the ecd2 LDPC handler) ---------------------------------
+
+class ReconCfg(C.Structure):
+    _fields_ = [("device", C.c_int), ("efficiency", C.c_float), ("n_rates", C.c_int), ("rates", C.c_float * 8),
+                ("n_ite", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("key_quantum", C.c_int),
+                ("max_blocks", C.c_int), ("seed", C.c_uint64), ("reserved", C.c_int * 8)]
+
+
+class ReconMsg(C.Structure):
+    _fields_ = [("rate_index", C.c_uint32), ("key_bits", C.c_uint32), ("code_k", C.c_uint32), ("code_m", C.c_uint32),
+                ("crc32", C.c_uint32)]
+
+
+_up = C.POINTER(C.c_uint32)
+_sig("qldpc_recon_cfg_default", None, [C.POINTER(ReconCfg)])
+_sig("qldpc_recon_create", C.c_int, [C.POINTER(ReconCfg), C.POINTER(_vp)])
+_sig("qldpc_recon_free", None, [_vp])
+_sig("qldpc_recon_plan", C.c_int, [_vp, C.c_int, C.c_float, C.POINTER(ReconMsg)])
+_sig("qldpc_recon_encode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, C.c_int])
+_sig("qldpc_recon_decode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
+_sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
+_sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
+
+
+def crc32_words(words, n_bits):
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    return int(_L.qldpc_crc32_words(w.ctypes.data_as(_up), int(n_bits)))
+
+
+class Recon:
+    """One side's reconciliation engine: what an ecd2 LDPC handler calls (qber_estim.c:337-340,420-423)."""
+
+    def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=50, rule="NMS", rule_param=0.75,
+                 key_quantum=1024, max_blocks=1, seed=7):
+        cfg = ReconCfg()
+        _L.qldpc_recon_cfg_default(C.byref(cfg))
+        cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
+        for i, r in enumerate(rates):
+            cfg.rates[i] = float(r)
+        cfg.n_ite, cfg.rule, cfg.rule_param = int(n_ite), RULES[rule], float(rule_param)
+        cfg.key_quantum, cfg.max_blocks, cfg.seed = int(key_quantum), int(max_blocks), int(seed)
+        h = _vp()
+        _chk(_L.qldpc_recon_create(C.byref(cfg), C.byref(h)), "Recon")
+        self._h = h
+        self.rates = tuple(rates)
+
+    def plan(self, key_bits, qber):
+        m = ReconMsg()
+        _chk(_L.qldpc_recon_plan(self._h, int(key_bits), float(qber), C.byref(m)), "Recon.plan")
+        return m
+
+    def encode(self, key_words, key_bits, qber):
+        """Alice: -> (msg, parity_words)."""
+        kw = np.ascontiguousarray(key_words, dtype=np.uint32)
+        m = self.plan(key_bits, qber)
+        par = np.zeros((m.code_m + 31) // 32, np.uint32)
+        _chk(_L.qldpc_recon_encode(self._h, kw.ctypes.data_as(_up), int(key_bits), float(qber), C.byref(m),
+                                   par.ctypes.data_as(_up), par.size), "Recon.encode")
+        return m, par
+
+    def decode(self, key_words, key_bits, qber, msg, parity_words):
+        """Bob: -> (ok, key_words, corrected_bits, leaked_bits, iterations); the returned copy is corrected."""
+        kw = np.array(key_words, dtype=np.uint32, copy=True)
+        par = np.ascontiguousarray(parity_words, dtype=np.uint32)
+        c, l, it = C.c_int(0), C.c_int(0), C.c_int(0)
+        rc = _L.qldpc_recon_decode(self._h, kw.ctypes.data_as(_up), int(key_bits), float(qber), C.byref(msg),
+                                   par.ctypes.data_as(_up), C.byref(c), C.byref(l), C.byref(it))
+        if rc not in (0, -9):
+            _chk(rc, "Recon.decode")
+        return rc == 0, kw, c.value, l.value, it.value
+
+    def decode_batch(self, key_words, key_bits, qber, msgs, parity_words):
+        kw = np.array(key_words, dtype=np.uint32, copy=True)
+        n = kw.shape[0]
+        par = np.ascontiguousarray(parity_words, dtype=np.uint32)
+        qb = np.ascontiguousarray(qber, dtype=np.float32)
+        arr = (ReconMsg * n)(*msgs)
+        st, co, it = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+        _chk(_L.qldpc_recon_decode_batch(self._h, n, kw.ctypes.data_as(_up), int(key_bits), qb.ctypes.data_as(_fp), arr,
+                                         par.ctypes.data_as(_up), st.ctypes.data_as(_ip), co.ctypes.data_as(_ip),
+                                         it.ctypes.data_as(_ip)), "Recon.decode_batch")
+        return st, kw, co, it
+
+    def __del__(self):
+        try:
+            _L.qldpc_recon_free(self._h)
+        except Exception:
+            pass

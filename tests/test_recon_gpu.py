@@ -1,0 +1,110 @@
+"""GPU suite: reconciliation sessions (Alice encode -> one parity message -> Bob decode + CRC verify)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def block(q, rng, key_bits, qber):
+    alice = rng.integers(0, 2, key_bits).astype(np.uint8)
+    bob = alice ^ (rng.random(key_bits) < qber)
+    return q.pack_bits(alice), q.pack_bits(bob), int((alice != bob).sum())
+
+
+@pytest.mark.parametrize("key_bits,qber", [(60000, 0.02), (41935, 0.035), (65535, 0.01), (5000, 0.05), (1000, 0.08)])
+def test_roundtrip_single_block(q, key_bits, qber):
+    rng = np.random.default_rng(key_bits)
+    r = q.Recon(max_blocks=1)
+    a, b, nerr = block(q, rng, key_bits, qber)
+    msg, par = r.encode(a, key_bits, qber)
+    assert msg.key_bits == key_bits and msg.code_k % 1024 == 0 and msg.code_k >= key_bits
+    assert par.size * 4 + 40 <= 10000 or msg.rate_index == 0     # one packet under transferd's 10 kB cap (rate 0.5 at 64 k bits needs two)
+    ok, fixed, corrected, leaked, it = r.decode(b, key_bits, qber, msg, par)
+    assert ok and corrected == nerr and leaked == msg.code_m + 32 and 1 <= it <= 50
+    assert (q.unpack_bits(fixed, key_bits) == q.unpack_bits(a, key_bits)).all()
+
+
+def test_rate_table_follows_min_cr(q):
+    r = q.Recon()
+    ps = (0.005, 0.01, 0.02, 0.03, 0.05, 0.08, 0.11)
+    got = [r.rates[r.plan(60000, p).rate_index] for p in ps]
+    for p, rate in zip(ps, got):
+        need = q.min_code_rate(p, 1.4)
+        assert rate <= need and all(x > need or x <= rate for x in r.rates)
+    assert got[0] == 0.9 and got[2] == 0.8 and got[-1] == 0.5
+    with pytest.raises(q.QldpcError) as e:
+        r.plan(60000, 0.3)
+    assert e.value.status == -7
+    m = r.plan(60000, 0.02)
+    assert (m.code_k, m.code_m) == (60416, 15104)
+
+
+def test_wrong_qber_estimate_fails_cleanly_and_leaves_key_untouched(q):
+    rng = np.random.default_rng(5)
+    r = q.Recon()
+    a, b, _ = block(q, rng, 20000, 0.12)                         # true error rate far above the estimate
+    msg, par = r.encode(a, 20000, 0.01)                          # planned for 1 %: rate 0.9
+    ok, fixed, corrected, leaked, it = r.decode(b, 20000, 0.01, msg, par)
+    assert not ok and corrected == 0 and (fixed == b).all() and it == 50
+
+
+def test_crc_catches_a_wrong_codeword(q):
+    rng = np.random.default_rng(6)
+    r = q.Recon()
+    a, b, _ = block(q, rng, 8000, 0.02)
+    msg, par = r.encode(a, 8000, 0.02)
+    msg.crc32 ^= 1
+    ok, fixed, *_ = r.decode(b, 8000, 0.02, msg, par)
+    assert not ok and (fixed == b).all()
+
+
+def test_header_mismatch_is_a_size_error(q):
+    r = q.Recon()
+    rng = np.random.default_rng(7)
+    a, b, _ = block(q, rng, 8000, 0.02)
+    msg, par = r.encode(a, 8000, 0.02)
+    with pytest.raises(q.QldpcError) as e:
+        r.decode(b, 7990, 0.02, msg, par)
+    assert e.value.status == -6
+
+
+def test_batch_of_epochs_multi_rate_stream(q):
+    """config 3 logic: per-epoch QBER ~ U[0.5 %, 6 %] (seed 42), rate picked per epoch, blocks of one plan batched."""
+    rng = np.random.default_rng(42)
+    r = q.Recon(max_blocks=16)
+    key_bits = 16000
+    qbers = rng.uniform(0.005, 0.06, 24).astype(np.float32)
+    groups = {}
+    for i, p in enumerate(qbers):
+        groups.setdefault(r.plan(key_bits, p).rate_index, []).append(i)
+    assert len(groups) >= 3
+    total_ok = 0
+    for idx, members in groups.items():
+        A, B, msgs, pars = [], [], [], []
+        for i in members:
+            a, b, _ = block(q, rng, key_bits, qbers[i])
+            m, par = r.encode(a, key_bits, qbers[i])
+            assert m.rate_index == idx
+            A.append(a); B.append(b); msgs.append(m); pars.append(par)
+        st, fixed, co, it = r.decode_batch(np.stack(B), key_bits, qbers[members], msgs, np.stack(pars))
+        for k in range(len(members)):
+            if st[k] == 0:
+                assert (fixed[k] == A[k]).all()
+                total_ok += 1
+            else:
+                assert (fixed[k] == B[k]).all()
+    assert total_ok >= 21
+
+
+def test_crc32_known_answer(q):
+    # IEEE 802.3 CRC-32 over the words' bytes, most significant byte first; whole words are hashed, the
+    # bits past n_bits masked to zero.  "123456789" + 3 zero bytes, and zlib as the independent reference.
+    import zlib
+    data = b"123456789"
+    bits = np.unpackbits(np.frombuffer(data, np.uint8))
+    assert q.crc32_words(q.pack_bits(bits), 72) == zlib.crc32(data + b"\0\0\0")
+    assert q.crc32_words(q.pack_bits(bits[:64]), 64) == zlib.crc32(data[:8])
+    assert zlib.crc32(data) == 0xCBF43926
+    junk = q.pack_bits(bits).copy()
+    junk[-1] |= 0x00FFFFFF                                      # garbage past n_bits must not matter
+    assert q.crc32_words(junk, 72) == zlib.crc32(data + b"\0\0\0")
