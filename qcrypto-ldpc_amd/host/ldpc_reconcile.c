@@ -1,0 +1,220 @@
+/*
+ * ldpc_reconcile.c -- LDPC reconciliation handlers for the qcrypto `ecd2` daemon (plain C host code).
+ * See ldpc_reconcile.h for where it hooks in.  Shape follows the sibling algorithm:
+ * cascade_initiateAfterQber (subcomponents/cascade_biconf.c:427-476) for the initiator,
+ * chooseEcAlgorithmAsQberFollower (subcomponents/qber_estim.c:293-345) for the role set-up, and the
+ * PA hand-over at cascade_biconf.c:892,939.  Every bit of arithmetic is behind libqldpc's C ABI.
+ */
+#include "ldpc_reconcile.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "subcomponents/comms.h"
+#include "subcomponents/debug.h"
+#include "subcomponents/helpers.h"
+#include "subcomponents/priv_amp.h"
+#include "subcomponents/processblock_mgmt.h"
+#include "definitions/proc_state.h"
+
+static qldpc_recon *g_recon = NULL;
+
+int ldpc_init(int device)
+{
+    qldpc_recon_cfg cfg;
+    if (g_recon) return 0;
+    qldpc_recon_cfg_default(&cfg);
+    cfg.device = device;
+    if (qldpc_recon_create(&cfg, &g_recon) != QLDPC_OK) {
+        fprintf(stderr, "ldpc_init: %s\n", qldpc_last_error());
+        return LDPC_ERR_ENGINE;
+    }
+    return 0;
+}
+
+void ldpc_shutdown(void)
+{
+    qldpc_recon_free(g_recon);
+    g_recon = NULL;
+}
+
+/* ---- data manager (definitions/algorithms/data_manager.h:28-32) ---------------------------- */
+
+static int initLdpcData(ProcessBlock *processBlock)
+{
+    if (processBlock->algorithmDataPtr) return 84;
+    processBlock->algorithmDataPtr = malloc2(sizeof(LdpcData));
+    if (!processBlock->algorithmDataPtr) return 34;
+    memset(processBlock->algorithmDataPtr, 0, sizeof(LdpcData));
+    return 0;
+}
+
+static int freeLdpcData(ProcessBlock *processBlock)
+{
+    free2(processBlock->algorithmDataPtr);
+    processBlock->algorithmDataPtr = NULL;
+    processBlock->algorithmDataMngr = NULL;
+    return 0;
+}
+
+const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC = {
+    ALG_DATATYPE_LDPC,
+    (const int (*)(ProcessBlock *))&initLdpcData,
+    (const int (*)(ProcessBlock *))&freeLdpcData
+};
+
+/* ---- packet managers: subtypes 8..10 on both sides ------------------------------------------ */
+
+static const PacketHandlerArray ALG_PKTHNDLRS_LDPC = {
+    privAmp_receivePrivAmpMsg,   /* subtype 8  */
+    ldpc_receiveParity,          /* subtype 9  */
+    ldpc_receiveVerdict          /* subtype 10 */
+};
+const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_INITIATOR = { &ALG_PKTHNDLRS_LDPC, SUBTYPE_START_PRIV_AMP, SUBTYPE_LDPC_VERDICT, False };
+const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FOLLOWER = { &ALG_PKTHNDLRS_LDPC, SUBTYPE_START_PRIV_AMP, SUBTYPE_LDPC_VERDICT, False };
+
+/* ---- helpers ---------------------------------------------------------------------------------- */
+
+/* comms_createEcHeader (subcomponents/comms.c:150-187) only knows subtypes 0..8; build ours the same way */
+static int ldpc_createHeader(char **buf, unsigned int subtype, unsigned int totalBytes, ProcessBlock *pb)
+{
+    EcPktHdr_Base *h;
+    *buf = malloc2(totalBytes);
+    if (!*buf) return 43;
+    memset(*buf, 0, totalBytes);
+    h = (EcPktHdr_Base *)*buf;
+    h->tag = EC_PACKET_TAG;
+    h->subtype = subtype;
+    h->totalLengthInBytes = totalBytes;
+    h->epoch = pb->startEpoch;
+    h->numberOfEpochs = pb->numberOfEpochs;
+    return 0;
+}
+
+static int ldpc_setup(ProcessBlock *pb, PROCESSOR_ROLE role)
+{
+    int errorCode;
+    if ((errorCode = ldpc_init(0))) return errorCode;
+    pb->processorRole = role;
+    pb->algorithmPktMngr = (ALGORITHM_PKT_MNGR *)(role == PROC_ROLE_EC_INITIATOR ? &ALG_PKT_MNGR_LDPC_INITIATOR : &ALG_PKT_MNGR_LDPC_FOLLOWER);
+    pb->algorithmDataMngr = (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC;
+    if ((errorCode = pb->algorithmDataMngr->initData(pb))) return errorCode;
+    /* compact out the bits revealed during QBER estimation: sets workbits, zeroes leakageBits
+     * (subcomponents/helpers.c:31-69); both sides do it, so both see the same workbits */
+    helper_cleanupRevealedBits(pb);
+    return 0;
+}
+
+/* ---- hooks for qber_estim.c ------------------------------------------------------------------- */
+
+int ldpc_prepareAsQberFollower(ProcessBlock *pb, ALGORITHM_DECISION chosenAlgorithm, char *ackToSend, unsigned int ackLength)
+{
+    int errorCode;
+    if (chosenAlgorithm == ALG_LDPC_CONTINUE_ROLES) {
+        /* QBER follower stays EC follower: ACK, then wait for the parity packet */
+        if ((errorCode = ldpc_setup(pb, PROC_ROLE_EC_FOLLOWER))) return errorCode;
+        return comms_insertSendPacket(ackToSend, ackLength);
+    }
+    /* ALG_LDPC_FLIP_ROLES: ACK first, then act as EC initiator */
+    if ((errorCode = ldpc_setup(pb, PROC_ROLE_EC_INITIATOR))) return errorCode;
+    if ((errorCode = comms_insertSendPacket(ackToSend, ackLength))) return errorCode;
+    return ldpc_initiateAfterQber(pb);
+}
+
+int ldpc_prepareAsQberInitiator(ProcessBlock *pb, ALGORITHM_DECISION chosenAlgorithm)
+{
+    int errorCode;
+    if (chosenAlgorithm == ALG_LDPC_CONTINUE_ROLES) {
+        if ((errorCode = ldpc_setup(pb, PROC_ROLE_EC_INITIATOR))) return errorCode;
+        return ldpc_initiateAfterQber(pb);
+    }
+    return ldpc_setup(pb, PROC_ROLE_EC_FOLLOWER);      /* wait for the other side's parity packet */
+}
+
+/* ---- EC initiator ("Alice"): one parity packet ------------------------------------------------- */
+
+int ldpc_initiateAfterQber(ProcessBlock *pb)
+{
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    qldpc_recon_msg msg;
+    EcPktHdr_LdpcParity *h9;
+    unsigned int parityWords, totalBytes;
+    int rc, errorCode;
+
+    rc = qldpc_recon_plan(g_recon, pb->workbits, pb->localError, &msg);
+    if (rc == QLDPC_EUNSUPPORTED) return LDPC_ERR_RATE;
+    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
+    parityWords = (msg.code_m + 31) / 32;
+    totalBytes = sizeof(EcPktHdr_LdpcParity) + parityWords * WORD_SIZE;
+    if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, totalBytes, pb))) return errorCode;
+
+    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (uint32_t *)&h9[1], (int)parityWords);
+    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(h9); return LDPC_ERR_ENGINE; }
+    h9->rateIndex = msg.rate_index;
+    h9->keyBits = msg.key_bits;
+    h9->codeK = msg.code_k;
+    h9->codeM = msg.code_m;
+    h9->crc32 = msg.crc32;
+    ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m;
+
+    pb->processingState = PSTATE_PERFORMED_PARITY;
+    pb->leakageBits += (int)msg.code_m + 32;            /* disclosed parity bits + CRC */
+    return comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
+}
+
+/* ---- EC follower ("Bob"): decode, verify, verdict, privacy amplification --------------------- */
+
+int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
+{
+    EcPktHdr_LdpcParity *in_head = (EcPktHdr_LdpcParity *)receivebuf;
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    EcPktHdr_LdpcVerdict *h10;
+    qldpc_recon_msg msg;
+    int corrected = 0, leaked = 0, iterations = 0, rc, errorCode;
+    unsigned int parityWords = (in_head->codeM + 31) / 32;
+
+    if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + parityWords * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
+    if ((int)in_head->keyBits != pb->workbits) return LDPC_ERR_PKT_SIZE;
+    msg.rate_index = in_head->rateIndex;
+    msg.key_bits = in_head->keyBits;
+    msg.code_k = in_head->codeK;
+    msg.code_m = in_head->codeM;
+    msg.crc32 = in_head->crc32;
+
+    /* the handler owns receivebuf only until it returns (ecd2.c:546-548): decode straight from it */
+    rc = qldpc_recon_decode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (const uint32_t *)&in_head[1], &corrected, &leaked, &iterations);
+    if (rc != QLDPC_OK && rc != QLDPC_EDECODE) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
+
+    if ((errorCode = ldpc_createHeader((char **)&h10, SUBTYPE_LDPC_VERDICT, sizeof(EcPktHdr_LdpcVerdict), pb))) return errorCode;
+    h10->decoded = (rc == QLDPC_OK);
+    h10->correctedBits = (unsigned int)corrected;
+    h10->iterations = (unsigned int)iterations;
+    if ((errorCode = comms_insertSendPacket((char *)h10, h10->base.totalLengthInBytes))) return errorCode;
+
+    if (rc == QLDPC_EDECODE) {
+        /* no codeword found or CRC mismatch: the block cannot be used */
+        pBlkMgmt_removeProcessBlk(pb->startEpoch);
+        return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
+    }
+    ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m; ld->iterations = iterations;
+    pb->correctedErrors = corrected;
+    pb->leakageBits += leaked;
+    pb->processingState = PSTATE_PERFORMED_PARITY;
+    /* same hand-over as cascade_biconf.c:892,939: send message 8 and do the PA locally */
+    return privAmp_sendPrivAmpMsgAndPrivAmp(pb);
+}
+
+/* ---- EC initiator: verdict ---------------------------------------------------------------------- */
+
+int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
+{
+    EcPktHdr_LdpcVerdict *in_head = (EcPktHdr_LdpcVerdict *)receivebuf;
+    if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) return LDPC_ERR_PKT_SIZE;
+    if (!in_head->decoded) {
+        pBlkMgmt_removeProcessBlk(pb->startEpoch);
+        return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
+    }
+    pb->correctedErrors = (int)in_head->correctedBits;
+    ((LdpcData *)pb->algorithmDataPtr)->iterations = (int)in_head->iterations;
+    return 0;   /* message 8 (privAmp_receivePrivAmpMsg) follows and finishes the block */
+}

@@ -1,0 +1,90 @@
+"""Two-process FIFO loopback of the reference's ecd2 daemon (SURVEY.md section 4's recipe).
+
+Alice (-s a2b -r b2a) and Bob (-s b2a -r a2b) talk over named pipes without transferd (it forwards EC
+packets unchanged, remotecrypto/transferd.c:766-768).  Inputs are synthetic stream-3 epoch files
+(packetheaders/pkt_header_3.h:4-12: {tag 3, epoch, length in bits, bitsperentry 1} + MSB-first words);
+outputs are the stream-7 final key files of both sides.  Test infrastructure only.
+"""
+import os
+import struct
+import subprocess
+import time
+
+import numpy as np
+
+
+def write_stream3(path, epoch, bits):
+    n = len(bits)
+    pad = (-n) % 32
+    b = np.concatenate([np.asarray(bits, np.uint8), np.zeros(pad, np.uint8)])
+    words = np.packbits(b).view(">u4").astype("<u4")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iIIi", 3, epoch, n, 1))
+        f.write(words.tobytes())
+
+
+def read_stream7(path):
+    raw = open(path, "rb").read()
+    tag, epoch, nepochs, nbits = struct.unpack("<iIIi", raw[:16])
+    words = np.frombuffer(raw[16:], "<u4")
+    return dict(tag=tag, epoch=epoch, nepochs=nepochs, nbits=nbits, words=words)
+
+
+def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180):
+    """alice_bits / bob_bits: lists of per-epoch 0/1 arrays. Returns dict with both final keys + logs."""
+    d = str(workdir)
+    for side in "ab":
+        for sub in ("raw", "final"):
+            os.makedirs(os.path.join(d, side, sub), exist_ok=True)
+    fifos = ["a_cmd", "b_cmd", "a2b", "b2a", "a_q", "b_q"]
+    for f in fifos:
+        p = os.path.join(d, f)
+        if not os.path.exists(p):
+            os.mkfifo(p)
+    for i, (a, b) in enumerate(zip(alice_bits, bob_bits)):
+        write_stream3(os.path.join(d, "a", "raw", "%08x" % (epoch0 + i)), epoch0 + i, a)
+        write_stream3(os.path.join(d, "b", "raw", "%08x" % (epoch0 + i)), epoch0 + i, b)
+    env = dict(os.environ)
+    env.update(env_extra or {})
+
+    def daemon(side, send, recv):
+        args = [binary, "-c", side + "_cmd", "-s", send, "-r", recv, "-d", side + "/raw", "-f", side + "/final",
+                "-l", side + "/notify", "-q", side + "/resp", "-Q", side + "_q", "-V", "5"]
+        log = open(os.path.join(d, side + ".log"), "w")
+        return subprocess.Popen(args, cwd=d, env=env, stdout=log, stderr=subprocess.STDOUT), log
+
+    pa, la = daemon("a", "a2b", "b2a")
+    pb, lb = daemon("b", "b2a", "a2b")
+    try:
+        time.sleep(0.5)
+        with open(os.path.join(d, "a_cmd"), "w") as f:
+            f.write("0x%08x %d\n" % (epoch0, len(alice_bits)))
+        fa = os.path.join(d, "a", "final", "%08x" % epoch0)
+        fb = os.path.join(d, "b", "final", "%08x" % epoch0)
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            if os.path.exists(fa) and os.path.exists(fb) and os.path.getsize(fa) > 16 and os.path.getsize(fb) > 16:
+                time.sleep(0.3)
+                break
+            if pa.poll() is not None or pb.poll() is not None:
+                break
+            time.sleep(0.1)
+    finally:
+        for p in (pa, pb):
+            if p.poll() is None:
+                p.terminate()
+        for p in (pa, pb):
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        la.close()
+        lb.close()
+    out = dict(a_log=open(os.path.join(d, "a.log")).read(), b_log=open(os.path.join(d, "b.log")).read(),
+               elapsed=time.time() - t0)
+    out["a_final"] = read_stream7(fa) if os.path.exists(fa) else None
+    out["b_final"] = read_stream7(fb) if os.path.exists(fb) else None
+    for side in "ab":
+        p = os.path.join(d, side, "notify")
+        out[side + "_notify"] = open(p).read() if os.path.exists(p) else ""
+    return out
