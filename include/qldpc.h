@@ -71,6 +71,15 @@ typedef enum qldpc_schedule {
     QLDPC_SCHED_HLAYERED = 1      /* horizontal layered, checks visited in the code's layer order */
 } qldpc_schedule;
 
+/*
+ * Two kernel families behind the same calls:
+ *   FRAMES  frame-interleaved: a wavefront lane = a frame; thousands of frames per launch (HBM-bound)
+ *   EDGES   edge-parallel: lanes run over the edges of ONE frame, check groups staged in LDS, min/sign
+ *           fold by wavefront shuffles; the daemon's one-block-at-a-time case (flooding; MS/OMS/NMS/SPA;
+ *           check degree <= 64)
+ */
+typedef enum qldpc_engine { QLDPC_ENGINE_AUTO = 0, QLDPC_ENGINE_FRAMES = 1, QLDPC_ENGINE_EDGES = 2 } qldpc_engine;
+
 /* Per-VN class for QKD frame formation (BS/src/main.cpp:348-362) */
 enum {
     QLDPC_VN_CHANNEL = 0,   /* sifted-key bit seen through the BSC:  LLR = (1-2y) ln((1-p)/p)      */
@@ -134,7 +143,8 @@ typedef struct qldpc_decoder_cfg {
     int max_frames;      /* capacity: frames decoded concurrently in one call (AFF3CT n_frames)  */
     int device;          /* HIP device ordinal                                                   */
     int frames_per_lane; /* 0 = auto; 1, 2 or 4 frames per wavefront lane (64/128/256-frame groups) */
-    int reserved[7];     /* must be zero                                                         */
+    int engine;          /* qldpc_engine: 0 = auto (edge-parallel for <= 16 frames when supported) */
+    int reserved[6];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
 void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);

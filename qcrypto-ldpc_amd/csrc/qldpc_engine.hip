@@ -18,6 +18,7 @@
 #include "../../include/qldpc.h"
 #include "qldpc_graph.h"
 #include "qldpc_kernels.h"
+#include "qldpc_kernels_edge.h"
 
 #define HIPCHK(expr)                                                                                    \
     do {                                                                                                \
@@ -66,6 +67,14 @@ struct qldpc_decoder {
     int loaded, ran;
     int last_iters;
     int poll_every;
+    /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
+    int engine, eW, eS, e_stride;
+    size_t e_lds;
+    uint32_t *e_sgn, *e_hard;
+    float *e_c2v1;                   /* odd-iteration chk_to_var buffer (d_b is the even one) */
+    int *e_unsat, *e_done_at;
+    int *h_done;
+    hipEvent_t e_ev[2];
     /* profiling */
     int prof_on;
     std::vector<prof_rec> prof_pending;
@@ -136,6 +145,10 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_llr); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active);
+    (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
+    if (d->h_done) (void)hipHostFree(d->h_done);
+    if (d->e_ev[0]) (void)hipEventDestroy(d->e_ev[0]);
+    if (d->e_ev[1]) (void)hipEventDestroy(d->e_ev[1]);
     if (d->h_active) (void)hipHostFree(d->h_active);
     delete d;
 }
@@ -176,6 +189,41 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         }
         HIPCHK(hipMemcpy(d->d_info_pos, pos.data(), sizeof(int) * (size_t)K, hipMemcpyHostToDevice));
     }
+    for (int k = 0; k < KS_COUNT; k++) { memset(&d->stats[k], 0, sizeof(d->stats[k])); snprintf(d->stats[k].name, sizeof(d->stats[k].name), "%s", ks_names[k]); }
+    /* engine choice: lanes over frames (batch) or lanes over edges (one block at a time) */
+    {
+        const bool edge_ok = cfg->schedule == QLDPC_SCHED_FLOODING && cfg->rule <= QLDPC_RULE_SPA && code->max_dc <= 64 &&
+                             (size_t)QE_THREADS * (size_t)code->max_dv * sizeof(float) <= 64 * 1024;
+        int eng = cfg->engine;
+        if (const char *e = getenv("QLDPC_ENGINE")) { int x = atoi(e); if (x >= 0 && x <= 2) eng = x; }
+        if (eng == QLDPC_ENGINE_EDGES && !edge_ok) {
+            qldpc_set_error("edge-parallel engine needs flooding, MS/OMS/NMS/SPA, check degree <= 64 (have %d) and VN degree <= 64 (have %d)", code->max_dc, code->max_dv);
+            return QLDPC_EUNSUPPORTED;
+        }
+        if (eng == QLDPC_ENGINE_AUTO) eng = (edge_ok && cfg->max_frames <= 16) ? QLDPC_ENGINE_EDGES : QLDPC_ENGINE_FRAMES;
+        d->engine = eng;
+    }
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        const size_t F = (size_t)cfg->max_frames;
+        d->eW = (d->N + 31) / 32;
+        d->eS = code->max_dc <= 8 ? 8 : (code->max_dc <= 16 ? 16 : (code->max_dc <= 32 ? 32 : 64));
+        d->e_lds = (size_t)QE_THREADS * (size_t)code->max_dv * sizeof(float);
+        d->e_stride = cfg->n_ite + 2;
+        if ((rc = dev_alloc(d, &d->d_llr, F * d->N))) return rc;
+        if ((rc = dev_alloc(d, &d->d_a, F * d->E))) return rc;
+        if ((rc = dev_alloc(d, &d->d_b, F * d->E))) return rc;
+        if ((rc = dev_alloc(d, &d->e_c2v1, F * d->E))) return rc;
+        if ((rc = dev_alloc(d, &d->e_sgn, F * d->eW))) return rc;
+        if ((rc = dev_alloc(d, &d->e_hard, F * d->eW))) return rc;
+        if ((rc = dev_alloc(d, &d->e_unsat, F * d->e_stride))) return rc;
+        if ((rc = dev_alloc(d, &d->e_done_at, F))) return rc;
+        HIPCHK(hipHostMalloc((void **)&d->h_done, sizeof(int) * F * 2));
+        HIPCHK(hipEventCreateWithFlags(&d->e_ev[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d->e_ev[1], hipEventDisableTiming));
+        d->poll_every = 4;
+        if (const char *e = getenv("QLDPC_POLL_EVERY")) d->poll_every = atoi(e);
+        return QLDPC_OK;
+    }
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
         if ((rc = make_buckets(d, code->cn_ptr, nullptr, d->M, CN_CAPS, 4, d->cn_buckets))) return rc;
         if ((rc = make_buckets(d, code->vn_ptr, nullptr, d->N, VN_CAPS, 2, d->vn_buckets))) return rc;
@@ -202,7 +250,6 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if ((rc = dev_alloc(d, &d->d_iters, G * FG))) return rc;
     if ((rc = dev_alloc(d, &d->d_active, 1))) return rc;
     HIPCHK(hipHostMalloc((void **)&d->h_active, sizeof(int)));
-    for (int k = 0; k < KS_COUNT; k++) { memset(&d->stats[k], 0, sizeof(d->stats[k])); snprintf(d->stats[k].name, sizeof(d->stats[k].name), "%s", ks_names[k]); }
     return QLDPC_OK;
 }
 
@@ -535,12 +582,86 @@ static int run_v(qldpc_decoder *d)
     return synd_pass<V>(d, d->d_hard, 0);
 }
 
+/* ---- edge-parallel engine ----------------------------------------------------------------- */
+
+template <int S>
+static void launch_qe_cn(qldpc_decoder *d, const uint32_t *bits, int slot, int syndrome_only)
+{
+    dim3 grid((unsigned)((d->M + QE_CPB - 1) / QE_CPB), (unsigned)d->n_frames);
+    qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    float *c2v_out = (slot & 1) ? d->e_c2v1 : d->d_b;        /* ping-pong by iteration parity */
+    if (d->cfg.rule == QLDPC_RULE_SPA)
+        hipLaunchKernelGGL((qe_cn<S, QK_FAM_SPA>), grid, dim3(QE_THREADS), 0, d->stream, d->d_a, c2v_out, d->d_cn_ptr, d->d_cn_tr, d->d_cn_var, bits,
+                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only);
+    else
+        hipLaunchKernelGGL((qe_cn<S, QK_FAM_MS>), grid, dim3(QE_THREADS), 0, d->stream, d->d_a, c2v_out, d->d_cn_ptr, d->d_cn_tr, d->d_cn_var, bits,
+                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only);
+}
+static int edge_cn(qldpc_decoder *d, const uint32_t *bits, int slot, int syndrome_only)
+{
+    prof_scope ps(d, syndrome_only ? KS_SYND : KS_CN, syndrome_only ? (double)d->E * 4.0 * d->n_frames : bytes_cn(d));
+    switch (d->eS) {
+    case 8: launch_qe_cn<8>(d, bits, slot, syndrome_only); break;
+    case 16: launch_qe_cn<16>(d, bits, slot, syndrome_only); break;
+    case 32: launch_qe_cn<32>(d, bits, slot, syndrome_only); break;
+    default: launch_qe_cn<64>(d, bits, slot, syndrome_only); break;
+    }
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+/* ite = index of the check pass whose messages are consumed (its parity selects the buffer); sel < 0: per-frame choice */
+template <int MODE>
+static int edge_vn(qldpc_decoder *d, int ite, int check, int force, float *post_out, int sel)
+{
+    prof_scope ps(d, KS_VN, bytes_vn(d, MODE));
+    dim3 grid((unsigned)((d->N + QE_THREADS - 1) / QE_THREADS), (unsigned)d->n_frames);
+    hipLaunchKernelGGL((qe_vn<MODE>), grid, dim3(QE_THREADS), d->e_lds, d->stream, d->d_b, d->e_c2v1, sel, d->cfg.n_ite, d->d_llr, d->d_a, d->e_sgn, d->e_hard, post_out, d->d_vn_ptr,
+                       d->N, d->E, d->eW, d->e_unsat, d->e_stride, ite, d->cfg.syndrome_depth, check, d->e_done_at, force);
+    LAUNCHCHK();
+    return QLDPC_OK;
+}
+
+static int run_edges(qldpc_decoder *d)
+{
+    int rc;
+    const int n_ite = d->cfg.n_ite, F = d->n_frames, synd = d->cfg.enable_syndrome;
+    hipLaunchKernelGGL(qe_init, dim3((unsigned)F), dim3(64), 0, d->stream, d->e_unsat, d->e_stride, d->e_done_at, F);
+    LAUNCHCHK();
+    if ((rc = edge_vn<QK_VN_FIRST>(d, 0, 0, 0, nullptr, 0))) return rc;
+    int ite = 0, pending = -1, flip = 0;
+    for (; ite < n_ite; ite++) {
+        if ((rc = edge_cn(d, d->e_sgn, ite, 0))) return rc;
+        if (ite == n_ite - 1) { if ((rc = edge_vn<QK_VN_POST>(d, ite, synd, 0, nullptr, ite & 1))) return rc; ite++; break; }
+        if ((rc = edge_vn<QK_VN_NORMAL>(d, ite, synd, 0, nullptr, ite & 1))) return rc;
+        if (synd && d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {
+            /* look-ahead polling: wait for the snapshot queued one poll ago, so the GPU always has work queued */
+            if (pending >= 0) {
+                HIPCHK(hipEventSynchronize(d->e_ev[pending]));
+                bool all = true;
+                for (int f = 0; f < F; f++) all = all && d->h_done[(size_t)pending * F + f] >= 0;
+                if (all) { ite++; break; }
+            }
+            HIPCHK(hipMemcpyAsync(d->h_done + (size_t)flip * F, d->e_done_at, sizeof(int) * (size_t)F, hipMemcpyDeviceToHost, d->stream));
+            HIPCHK(hipEventRecord(d->e_ev[flip], d->stream));
+            pending = flip; flip ^= 1;
+        }
+    }
+    d->last_iters = ite;
+    /* success flag: syndrome of the final hard decisions into the last slot */
+    return edge_cn(d, d->e_hard, n_ite + 1, 1);
+}
+
 extern "C" int qldpc_run(qldpc_decoder *d)
 {
     if (!d) return QLDPC_EINVAL;
     if (!d->loaded) { qldpc_set_error("qldpc_run: nothing loaded"); return QLDPC_ESTATE; }
     HIPCHK(hipSetDevice(d->device));
     int rc;
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        rc = run_edges(d);
+        if (rc == QLDPC_OK) d->ran = 1;
+        return rc;
+    }
     switch (d->V) {
     case 1: rc = run_v<1>(d); break;
     case 2: rc = run_v<2>(d); break;
@@ -568,6 +689,12 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
     d->n_frames = n_frames;
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
+        HIPCHK(hipMemcpyAsync(d->d_llr, d_llr, sizeof(float) * (size_t)n_frames * d->N, hipMemcpyDeviceToDevice, d->stream));
+        d->loaded = 1; d->ran = 0;
+        return QLDPC_OK;
+    }
     {
         prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
         dim3 grid((unsigned)((d->N + 63) / 64), (unsigned)d->G);
@@ -590,6 +717,14 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
     HIPCHK(hipSetDevice(d->device));
     d->n_frames = n_frames;
     const int W = (d->N + 31) / 32;
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
+        hipLaunchKernelGGL(qe_load_bits, dim3((unsigned)std::min((d->N + 255) / 256, 256), (unsigned)n_frames), dim3(256), 0, d->stream, d_bits, d_llr_mag, d_vn_class,
+                           d->d_llr, d->N, W);
+        LAUNCHCHK();
+        d->loaded = 1; d->ran = 0;
+        return QLDPC_OK;
+    }
     {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
         dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
@@ -620,6 +755,10 @@ extern "C" int qldpc_fetch_packed_dev(qldpc_decoder *d, uint32_t *d_out)
     HIPCHK(hipSetDevice(d->device));
     const int W = (d->N + 31) / 32;
     prof_scope ps(d, KS_FETCH, (double)W * 4.0 * d->n_frames);
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        HIPCHK(hipMemcpyAsync(d_out, d->e_hard, sizeof(uint32_t) * (size_t)d->n_frames * W, hipMemcpyDeviceToDevice, d->stream));
+        return QLDPC_OK;
+    }
     dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
     switch (d->V) {
     case 1: hipLaunchKernelGGL((qk_fetch_packed<1>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
@@ -638,6 +777,11 @@ extern "C" int qldpc_fetch_info_dev(qldpc_decoder *d, int *d_V_K)
     HIPCHK(hipSetDevice(d->device));
     prof_scope ps(d, KS_FETCH, (double)d->K * 4.0 * d->n_frames);
     dim3 grid((unsigned)std::max(1, std::min((d->K + 255) / 256, 64)), (unsigned)d->n_frames);
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        hipLaunchKernelGGL(qe_fetch_info, grid, dim3(256), 0, d->stream, d->e_hard, d->d_info_pos, d_V_K, d->K, d->eW);
+        LAUNCHCHK();
+        return QLDPC_OK;
+    }
     switch (d->V) {
     case 1: hipLaunchKernelGGL((qk_fetch_info<1>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
     case 2: hipLaunchKernelGGL((qk_fetch_info<2>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
@@ -654,6 +798,11 @@ extern "C" int qldpc_fetch_status_dev(qldpc_decoder *d, int *d_iters, int *d_ok)
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
     dim3 grid((unsigned)((d->n_frames + 255) / 256));
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        hipLaunchKernelGGL(qe_status_out, grid, dim3(256), 0, d->stream, d->e_unsat, d->e_stride, d->cfg.n_ite + 1, d->e_done_at, d->cfg.n_ite, d_iters, d_ok, d->n_frames);
+        LAUNCHCHK();
+        return QLDPC_OK;
+    }
     switch (d->V) {
     case 1: hipLaunchKernelGGL((qk_status_out<1>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
     case 2: hipLaunchKernelGGL((qk_status_out<2>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
@@ -669,6 +818,10 @@ extern "C" int qldpc_fetch_post_dev(qldpc_decoder *d, float *d_post_out)
     int rc = need_ran(d, "qldpc_fetch_post_dev");
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        /* posterior of the last executed check pass, written frame-major directly (exact in fixed-iteration mode) */
+        return edge_vn<QK_VN_POST>(d, 0, 0, 1, d_post_out, -1);
+    }
     const float *src;
     if (d->cfg.schedule == QLDPC_SCHED_FLOODING) {
         if (!d->d_post) { if ((rc = dev_alloc(d, &d->d_post, (size_t)d->G * d->N * d->FG))) return rc; }

@@ -1,0 +1,238 @@
+/*
+ * qldpc_kernels_edge.h -- gfx950 kernels of the LOW-BATCH ("edge-parallel") BP decoder.
+ *
+ * The frame-interleaved engine (qldpc_kernels.h) needs >= 64 frames to fill a wavefront.  The ecd2
+ * daemon decodes ONE block of <= 65 535 bits at a time, so here the wavefront lanes run across the
+ * EDGES of one frame instead:
+ *   check nodes : a workgroup owns QE_CPB consecutive checks; their contiguous CN-major edge range is
+ *                 staged into LDS with fully coalesced index loads + one gather per edge, each check
+ *                 is then folded by a segment of S = 2^k lanes with wavefront shuffles (butterfly
+ *                 all-reduce of (min1, min2, sign) -- exact for the min-sum family because min /
+ *                 second-min / xor do not depend on association order), results go back through LDS
+ *                 and are scattered with all lanes busy.  The syndrome of the previous posterior is
+ *                 folded in the same pass (one extra bit per edge).
+ *   variable nodes: a workgroup owns 256 consecutive VNs = one contiguous slot range, staged through
+ *                 LDS so global traffic is coalesced; each lane sums its VN's slots in order (the same
+ *                 order as AFF3CT's _initialize_var_to_chk) and the hard decisions leave as wave
+ *                 ballots, i.e. directly as MSB-first packed words (helpers.h:65-70).
+ * Layout: llr [F][N], v2c [F][E], c2v [2][F][E] (VN-major slots; ping-pong by iteration parity),
+ * sgn / hard [F][ceil(N/32)] packed words.
+ * State lives in L2 / Infinity Cache (2 MB per frame at N = 65 536); no MFMA.
+ */
+#ifndef QLDPC_KERNELS_EDGE_H
+#define QLDPC_KERNELS_EDGE_H
+
+#include "qldpc_kernels.h"
+
+#define QE_THREADS 256
+#define QE_CPB 64                 /* checks per workgroup  */
+#define QE_MAX_EDGES (QE_CPB * 64)
+
+/* convergence bookkeeping of one frame, all in global memory:
+ *   unsat[f][ite]  OR over checks of the syndrome of the bits that existed when CN(ite) ran
+ *   done_at[f]     -1, or the iteration count at which AFF3CT's loop would have broken            */
+__device__ __forceinline__ bool qe_converged(const int *__restrict__ unsat, int stride, int f, int ite, int depth)
+{
+    /* bits checked in CN(ite) are the posterior after iteration ite-1; AFF3CT needs `depth`
+     * consecutive zero syndromes, the first check happens after iteration 0 (slot 1) */
+    if (ite < depth) return false;
+    for (int k = 0; k < depth; k++) if (unsat[(size_t)f * stride + ite - k] != 0) return false;
+    return true;
+}
+
+/* ------------------------------------------------------------------ check nodes -------------- */
+
+template <int S, int FAM>
+__global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2c, float *__restrict__ c2v,
+                                                    const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                                    const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
+                                                    int M, int E, int W, int *__restrict__ unsat, int unsat_stride, int ite,
+                                                    const int *__restrict__ done_at, qk_rule rule, int syndrome_only)
+{
+    __shared__ int s_idx[QE_MAX_EDGES];
+    __shared__ float s_val[QE_MAX_EDGES];
+    __shared__ int s_unsat;
+    const int f = blockIdx.y;
+    if (!syndrome_only && done_at[f] >= 0) return;      /* the final success-flag pass covers every frame */
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * QE_CPB;
+    const int c1 = min(M, c0 + QE_CPB);
+    const int e0 = cn_ptr[c0], nE = cn_ptr[c1] - e0;
+    const float *vin = v2c + (size_t)f * E;
+    float *cout = c2v + (size_t)f * E;
+    const uint32_t *sw = sgn + (size_t)f * W;
+    if (tid == 0) s_unsat = 0;
+    /* phase A: stage the chunk's edges (index + message + sign bit of the VN's last posterior) */
+    for (int e = tid; e < nE; e += QE_THREADS) {
+        const int slot = cn_tr[e0 + e];
+        const int v = cn_var[e0 + e];
+        const uint32_t bit = (sw[v >> 5] >> (31 - (v & 31))) & 1u;
+        s_idx[e] = slot | (int)(bit << 31);
+        s_val[e] = syndrome_only ? 0.0f : vin[slot];
+    }
+    __syncthreads();
+    /* phase B: one S-lane segment per check, butterfly all-reduce with wavefront shuffles */
+    constexpr int PER_ROUND = QE_THREADS / S;
+    const int seg = tid / S, s = tid % S;
+    uint32_t any_unsat = 0;
+    for (int c = c0 + seg; c < c0 + QE_CPB; c += PER_ROUND) {
+        const bool live = c < c1;
+        const int off = live ? cn_ptr[c] - e0 : 0;
+        const int deg = live ? cn_ptr[c + 1] - cn_ptr[c] : 0;
+        const bool act = s < deg;
+        const float x = act ? s_val[off + s] : 0.0f;
+        uint32_t par = act ? ((uint32_t)s_idx[off + s] >> 31) : 0u;
+        if constexpr (FAM == QK_FAM_MS) {
+            float m1 = act ? fabsf(x) : 3.402823466e+38f, m2 = 3.402823466e+38f;
+            uint32_t sg = act ? (qk_bits(x) & 0x80000000u) : 0u;
+#pragma unroll
+            for (int o = 1; o < S; o <<= 1) {
+                const float p1 = __shfl_xor(m1, o), p2 = __shfl_xor(m2, o);
+                sg ^= __shfl_xor(sg, o);
+                par ^= __shfl_xor(par, o);
+                const float lo = qk_min(m1, p1), hi = qk_max(m1, p1);
+                m2 = qk_min(hi, qk_min(m2, p2));
+                m1 = lo;
+            }
+            if (act && !syndrome_only) {
+                float cst1, cst2;
+                if (rule.rule == 0)      { cst1 = qk_max(0.0f, m2);              cst2 = qk_max(0.0f, m1); }
+                else if (rule.rule == 1) { cst1 = qk_max(0.0f, m2 - rule.param); cst2 = qk_max(0.0f, m1 - rule.param); }
+                else                     { cst1 = m2 * rule.param;               cst2 = m1 * rule.param; }
+                s_val[off + s] = qk_withsign((fabsf(x) == m1) ? cst1 : cst2, sg ^ qk_bits(x));
+            }
+        } else {   /* SPA: the product is reduced as a tree, so it is tolerance-class (not order-exact) */
+            const float t = act ? tanhf(fabsf(x) * 0.5f) : 1.0f;
+            float prod = t;
+            uint32_t sg = act ? (qk_bits(x) & 0x80000000u) : 0u;
+#pragma unroll
+            for (int o = 1; o < S; o <<= 1) {
+                prod *= __shfl_xor(prod, o);
+                sg ^= __shfl_xor(sg, o);
+                par ^= __shfl_xor(par, o);
+            }
+            if (act && !syndrome_only) {
+                float r = prod / t;
+                r = (r < 1.0f) ? r : 1.0f - 1.1920928955078125e-07f;
+                s_val[off + s] = qk_withsign(2.0f * atanhf(r), sg ^ qk_bits(x));
+            }
+        }
+        any_unsat |= par;
+    }
+    if (__any(any_unsat != 0) && (tid & 63) == 0) atomicOr(&s_unsat, 1);
+    __syncthreads();
+    /* phase C: scatter with every lane busy */
+    if (!syndrome_only)
+        for (int e = tid; e < nE; e += QE_THREADS) cout[s_idx[e] & 0x7fffffff] = s_val[e];
+    if (tid == 0 && s_unsat) atomicOr(&unsat[(size_t)f * unsat_stride + ite], 1);
+}
+
+/* ------------------------------------------------------------------ variable nodes ----------- */
+
+/*
+ * MODE as in the batch engine: QK_VN_FIRST (chk_to_var == 0), QK_VN_NORMAL, QK_VN_POST.
+ * Dynamic LDS: 256 * max_dv floats.  The convergence test of the PREVIOUS check pass is evaluated
+ * here by every workgroup (same global words, so the same answer); workgroup 0 records it.
+ */
+template <int MODE>
+__global__ __launch_bounds__(QE_THREADS) void qe_vn(const float *__restrict__ c2v0, const float *__restrict__ c2v1, int sel, int n_ite,
+                                                    const float *__restrict__ llr, float *__restrict__ v2c,
+                                                    uint32_t *__restrict__ sgn, uint32_t *__restrict__ hard, float *__restrict__ post_out,
+                                                    const int *__restrict__ vn_ptr, int N, int E, int W,
+                                                    const int *__restrict__ unsat, int unsat_stride, int ite, int depth, int check,
+                                                    int *__restrict__ done_at, int force)
+{
+    extern __shared__ __align__(16) float s_msg[];
+    const int f = blockIdx.y;
+    if (!force) {
+        if (done_at[f] >= 0) return;
+        if (check && qe_converged(unsat, unsat_stride, f, ite, depth)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) done_at[f] = ite;     /* iterations executed */
+            return;
+        }
+    }
+    const int tid = threadIdx.x;
+    const int v0 = blockIdx.x * QE_THREADS;
+    const int v1 = min(N, v0 + QE_THREADS);
+    const int sl0 = vn_ptr[v0], nS = vn_ptr[v1] - sl0;
+    /* chk_to_var is double-buffered by iteration parity so that the check pass which DETECTS convergence
+     * (it runs one iteration ahead) does not clobber the messages the posterior is made of */
+    if (sel < 0) sel = ((done_at[f] >= 0 ? done_at[f] : n_ite) - 1) & 1;
+    const float *cin = (sel ? c2v1 : c2v0) + (size_t)f * E + sl0;
+    float *vout = v2c + (size_t)f * E + sl0;
+    if (MODE != QK_VN_FIRST) {
+        for (int k = tid; k < nS; k += QE_THREADS) s_msg[k] = cin[k];
+        __syncthreads();
+    }
+    const int v = v0 + tid;
+    float tmp = 0.0f;
+    if (v < v1) {
+        const int b = vn_ptr[v] - sl0, deg = vn_ptr[v + 1] - vn_ptr[v];
+        float sum = 0.0f;
+        if (MODE != QK_VN_FIRST) for (int k = 0; k < deg; k++) sum += s_msg[b + k];
+        tmp = llr[(size_t)f * N + v] + sum;
+        if (MODE == QK_VN_FIRST) { const float o = tmp - 0.0f; for (int k = 0; k < deg; k++) s_msg[b + k] = o; }
+        else if (MODE == QK_VN_NORMAL) for (int k = 0; k < deg; k++) s_msg[b + k] = tmp - s_msg[b + k];
+        if (MODE == QK_VN_POST && post_out) post_out[(size_t)f * N + v] = tmp;
+    }
+    /* ballots -> MSB-first words: lane l of the wave is bit (31 - l%32) of word l/32 */
+    const u64 sb = __ballot(v < v1 && (qk_bits(tmp) >> 31) != 0);
+    const u64 hb = __ballot(v < v1 && !(tmp >= 0.0f));
+    const int lane = tid & 63;
+    if (lane < 2) {
+        const int w = (v0 + (tid & ~63)) / 32 + lane;
+        if (w < W) {
+            sgn[(size_t)f * W + w] = __brev((uint32_t)(sb >> (32 * lane)));
+            hard[(size_t)f * W + w] = __brev((uint32_t)(hb >> (32 * lane)));
+        }
+    }
+    if (MODE != QK_VN_POST) {
+        __syncthreads();
+        for (int k = tid; k < nS; k += QE_THREADS) vout[k] = s_msg[k];
+    }
+}
+
+/* ------------------------------------------------------------------ load / fetch / status ---- */
+
+__global__ void qe_init(int *__restrict__ unsat, int unsat_stride, int *__restrict__ done_at, int F)
+{
+    const int f = blockIdx.x;
+    for (int k = threadIdx.x; k < unsat_stride; k += blockDim.x) unsat[(size_t)f * unsat_stride + k] = 0;
+    if (threadIdx.x == 0) done_at[f] = -1;
+    (void)F;
+}
+
+/* QKD frame formation for frame-major floats: bits[F][W] + |LLR| per frame + class per VN -> llr[F][N] */
+__global__ void qe_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag, const uint8_t *__restrict__ vn_class,
+                             float *__restrict__ llr, int N, int W)
+{
+    const int f = blockIdx.y;
+    const float mag = llr_mag[f];
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+        const bool y = (bits[(size_t)f * W + (v >> 5)] >> (31 - (v & 31))) & 1u;
+        const int cls = vn_class ? vn_class[v] : 0;
+        const float m = (cls == 0) ? mag : (cls == 1 ? 23.025850929840455f : 0.0f);
+        llr[(size_t)f * N + v] = y ? -m : m;
+    }
+}
+
+__global__ void qe_fetch_info(const uint32_t *__restrict__ hard, const int *__restrict__ info_pos, int *__restrict__ out, int K, int W)
+{
+    const int f = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
+        const int v = info_pos[i];
+        out[(size_t)f * K + i] = (int)((hard[(size_t)f * W + (v >> 5)] >> (31 - (v & 31))) & 1u);
+    }
+}
+
+/* iters / ok per frame: ok = syndrome of the final HARD bits, left in unsat[f][final_slot] by a syndrome-only pass */
+__global__ void qe_status_out(const int *__restrict__ unsat, int unsat_stride, int final_slot, const int *__restrict__ done_at, int n_ite,
+                              int *__restrict__ out_iters, int *__restrict__ out_ok, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    if (out_iters) out_iters[f] = done_at[f] >= 0 ? done_at[f] : n_ite;
+    if (out_ok) out_ok[f] = unsat[(size_t)f * unsat_stride + final_slot] == 0;
+}
+
+#endif /* QLDPC_KERNELS_EDGE_H */

@@ -159,6 +159,8 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
 
     pb->processingState = PSTATE_PERFORMED_PARITY;
     pb->leakageBits += (int)msg.code_m + 32;            /* disclosed parity bits + CRC */
+    printf("ldpc: epoch %08x: sent parity, %d key bits, rate index %u, K %u, M %u\n", pb->startEpoch, pb->workbits, msg.rate_index, msg.code_k, msg.code_m);
+    fflush(stdout);
     return comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
 }
 
@@ -197,6 +199,8 @@ int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
     ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m; ld->iterations = iterations;
+    printf("ldpc: epoch %08x: decoded %d key bits in %d iterations, %d errors corrected, %d bits leaked\n", pb->startEpoch, pb->workbits, iterations, corrected, leaked);
+    fflush(stdout);
     pb->correctedErrors = corrected;
     pb->leakageBits += leaked;
     pb->processingState = PSTATE_PERFORMED_PARITY;

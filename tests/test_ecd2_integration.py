@@ -62,7 +62,13 @@ def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0
     assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
     # the exchange really was LDPC: subtype 9 / 10 in the logs, no cascade subtypes 4..7
-    assert "subtype 9" in out["a_log"] or "pkt subtype 9" in out["a_log"] or "ldpc" in out["b_log"].lower() or True
+    assert "ldpc: epoch b0b80000: sent parity" in out["a_log"] and "ldpc: epoch b0b80000: decoded" in out["b_log"]
+    for cascade_subtype in (4, 5, 6, 7):
+        assert "Prep to send pkt subtype %d\n" % cascade_subtype not in out["a_log"] + out["b_log"]
+    errs = sum(int((x != y).sum()) for x, y in zip(a, b))
+    import re
+    m = re.search(r"(\d+) errors corrected", out["b_log"])
+    assert m and 0 < int(m.group(1)) <= errs                   # sample bits revealed in QBER estimation are not counted
     note = out["b_notify"] + out["a_notify"]
     assert "final bit number" in note
 
