@@ -143,7 +143,7 @@ typedef struct qldpc_decoder_cfg {
     int max_frames;      /* capacity: frames decoded concurrently in one call (AFF3CT n_frames)  */
     int device;          /* HIP device ordinal                                                   */
     int frames_per_lane; /* 0 = auto; 1, 2 or 4 frames per wavefront lane (64/128/256-frame groups) */
-    int engine;          /* qldpc_engine: 0 = auto (edge-parallel for <= 16 frames when supported) */
+    int engine;          /* qldpc_engine: 0 = auto (edge-parallel for <= 8 frames when supported) */
     int reserved[6];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 

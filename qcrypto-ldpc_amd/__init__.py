@@ -24,6 +24,28 @@ if not os.path.exists(LIB_PATH):
         "libqldpc.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
         "`make -C qcrypto-ldpc_amd/csrc`. There is no CPU fallback." % LIB_PATH)
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 (soname libamdhip64.so.7, requested by file name).
+    If libqldpc pulled /opt/rocm's copy in first, a later `import torch` would load a SECOND HIP runtime and
+    whichever initialises last sees no GPU.  Loading torch's copy first makes both share one runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        p = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
+_preload_torch_hip_runtime()
 _L = C.CDLL(LIB_PATH)
 
 RULES = {"MS": 0, "OMS": 1, "NMS": 2, "SPA": 3, "LSPA": 4, "AMS_MIN": 5, "AMS_MINSTAR_L2": 6, "AMS_MINSTAR": 7}

@@ -200,7 +200,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
             qldpc_set_error("edge-parallel engine needs flooding, MS/OMS/NMS/SPA, check degree <= 64 (have %d) and VN degree <= 64 (have %d)", code->max_dc, code->max_dv);
             return QLDPC_EUNSUPPORTED;
         }
-        if (eng == QLDPC_ENGINE_AUTO) eng = (edge_ok && cfg->max_frames <= 16) ? QLDPC_ENGINE_EDGES : QLDPC_ENGINE_FRAMES;
+        if (eng == QLDPC_ENGINE_AUTO) eng = (edge_ok && cfg->max_frames <= 8) ? QLDPC_ENGINE_EDGES : QLDPC_ENGINE_FRAMES;
         d->engine = eng;
     }
     if (d->engine == QLDPC_ENGINE_EDGES) {
