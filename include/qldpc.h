@@ -269,6 +269,18 @@ int qldpc_recon_decode_batch(qldpc_recon *r, int n_blocks, uint32_t *key_words, 
                              int *corrected_bits, int *iterations);
 uint32_t qldpc_crc32_words(const uint32_t *words, int n_bits);
 
+/* ------------------------------------------------------------------ privacy amplification ---- */
+/*
+ * The hash loop of privAmp_doPrivAmp (subcomponents/priv_amp.c:213-218) with the LFSR word stream of
+ * rnd_getPrngValue2_32 (subcomponents/rnd.c:118-127, feedback 0xe0000200): final key bit i =
+ * parity(XOR_j key[j] & w[i*numwords + j]).  key = mainBufPtr words (bits past workbits are ignored),
+ * seed = EcPktHdr_StartPrivAmp.seed (definitions/packets.h:170-175), out = ceil(final_bits/32) words.
+ * Pure integer arithmetic: bit-identical to the reference.
+ */
+int qldpc_privamp(int device, const uint32_t *key_words, int workbits, uint32_t seed, int final_bits, uint32_t *final_words);
+/* device pointers; the key's tail bits past workbits must already be zero */
+int qldpc_privamp_dev(const uint32_t *d_key_words, int workbits, uint32_t seed, int final_bits, uint32_t *d_final_words, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

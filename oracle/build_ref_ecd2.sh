@@ -21,6 +21,8 @@ chmod -R u+w "$TMP"
 cd "$TMP/errorcorrection"
 SRCS="subcomponents/rnd.c subcomponents/debug.c subcomponents/helpers.c subcomponents/comms.c subcomponents/cascade_biconf.c subcomponents/priv_amp.c subcomponents/qber_estim.c subcomponents/processblock_mgmt.c definitions/algorithms/algorithms.c ecd2.c"
 gcc -O2 -g -w -o "$OUT/ecd2_cascade" $SRCS -lm
+# the reference's own PRNG (subcomponents/rnd.c) as a shared object: pins the oracle's LFSR restatement
+gcc -O2 -w -shared -fPIC -o "$OUT/librefrnd.so" subcomponents/rnd.c
 
 # ---- maintainer edits on the scratch copy ----
 python3 - <<'PY'

@@ -52,6 +52,11 @@ def lib():
                                  fp, ip, ip, ip, C.c_int]
         L.orc_syndrome.restype = C.c_int
         L.orc_syndrome.argtypes = [C.c_void_p, ip, ip]
+        up = C.POINTER(C.c_uint32)
+        L.orc_lfsr32.restype = C.c_uint32
+        L.orc_lfsr32.argtypes = [up]
+        L.orc_privamp.restype = None
+        L.orc_privamp.argtypes = [up, C.c_int, C.c_uint32, C.c_int, up]
         _lib = L
     return _lib
 
@@ -134,3 +139,28 @@ def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", ena
     if rc != 0:
         raise RuntimeError("orc_decode failed: %d" % rc)
     return dict(post=post, hard=hard, iters=iters, synd_ok=ok)
+
+
+def lfsr32_stream(seed, n):
+    """n successive outputs of the restated rnd_getPrngValue2_32."""
+    st = C.c_uint32(seed)
+    return np.array([lib().orc_lfsr32(C.byref(st)) for _ in range(n)], np.uint32)
+
+
+def privamp(key_words, workbits, seed, final_bits):
+    kw = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros((final_bits + 31) // 32, np.uint32)
+    up = C.POINTER(C.c_uint32)
+    lib().orc_privamp(kw.ctypes.data_as(up), int(workbits), int(seed), int(final_bits), out.ctypes.data_as(up))
+    return out
+
+
+def ref_rnd():
+    """The reference's own subcomponents/rnd.c as built by oracle/build_ref_ecd2.sh (None when absent)."""
+    p = os.path.join(_HERE, "_ref", "librefrnd.so")
+    if not os.path.exists(p):
+        return None
+    R = C.CDLL(p)
+    R.rnd_getPrngValue2_32.restype = C.c_uint32
+    R.rnd_getPrngValue2_32.argtypes = [C.POINTER(C.c_uint32)]
+    return R

@@ -436,3 +436,34 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
     }
     return 0;
 }
+
+/* ------------------------------------------------------------- privacy amplification ----- */
+
+/* rnd_getPrngValue2_32 (EC/subcomponents/rnd.c:118-127): 32 x { b = parity(state & 0xe0000200); state <<= 1; state += b } */
+unsigned int orc_lfsr32(unsigned int *state)
+{
+    for (int k = 32; k; k--) {
+        const unsigned int b = (unsigned int)__builtin_parity(*state & 0xe0000200u);
+        *state <<= 1;
+        *state += b;
+    }
+    return *state;
+}
+
+/* privAmp_doPrivAmp, EC/subcomponents/priv_amp.c:194-218: mask the tail of the key, then for every target bit
+ * m = XOR_j key[j] & prng32(); bit i = parity(m); words MSB-first (uint32AllZeroExceptAtN, helpers.h:68) */
+void orc_privamp(const unsigned int *key_words, int workbits, unsigned int seed, int final_bits, unsigned int *final_words)
+{
+    const int numwords = (workbits + 31) / 32;
+    unsigned int *key = (unsigned int *)malloc(sizeof(unsigned int) * (size_t)numwords);
+    memcpy(key, key_words, sizeof(unsigned int) * (size_t)numwords);
+    if (workbits & 31) key[numwords - 1] &= 0xffffffffu << (32 - (workbits & 31));
+    memset(final_words, 0, sizeof(unsigned int) * (size_t)((final_bits + 31) / 32));
+    unsigned int state = seed;
+    for (int i = 0; i < final_bits; i++) {
+        unsigned int m = 0;
+        for (int j = 0; j < numwords; j++) m ^= key[j] & orc_lfsr32(&state);
+        if (__builtin_parity(m)) final_words[i / 32] |= 1u << (31 - (i & 31));
+    }
+    free(key);
+}

@@ -71,6 +71,14 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
                int enable_syndrome, int syndrome_depth, const float *Y_N, int n_frames,
                float *post, int *hard, int *iters, int *synd_ok, int n_threads);
 
+/*
+ * Privacy amplification hash, restating privAmp_doPrivAmp's loop (EC/subcomponents/priv_amp.c:213-218)
+ * and the bit-serial LFSR of rnd_getPrngValue2_32 (EC/subcomponents/rnd.c:118-127, PRNG_FEEDBACK
+ * 0xe0000200 rnd.h:46).  Pinned against the reference's own rnd.c compiled into oracle/_ref/librefrnd.so.
+ */
+unsigned int orc_lfsr32(unsigned int *state);
+void orc_privamp(const unsigned int *key_words, int workbits, unsigned int seed, int final_bits, unsigned int *final_words);
+
 /* H * x over GF(2) for one word x[N] of 0/1 ints -> s[M]. Returns syndrome weight. */
 int orc_syndrome(const orc_graph *g, const int *x, int *s);
 

@@ -461,6 +461,19 @@ _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.PO
 _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
 
 
+_sig("qldpc_privamp", C.c_int, [C.c_int, _up, C.c_int, C.c_uint32, C.c_int, _up])
+_sig("qldpc_privamp_dev", C.c_int, [_vp, C.c_int, C.c_uint32, C.c_int, _vp, _vp])
+
+
+def privamp(key_words, workbits, seed, final_bits, device=0):
+    """privAmp_doPrivAmp's hash (priv_amp.c:213-218) on the GPU: -> ceil(final_bits/32) words, MSB-first."""
+    kw = np.ascontiguousarray(key_words, dtype=np.uint32)
+    out = np.zeros((int(final_bits) + 31) // 32, np.uint32)
+    _chk(_L.qldpc_privamp(int(device), kw.ctypes.data_as(_up), int(workbits), int(seed) & 0xFFFFFFFF, int(final_bits),
+                          out.ctypes.data_as(_up)), "privamp")
+    return out
+
+
 def crc32_words(words, n_bits):
     w = np.ascontiguousarray(words, dtype=np.uint32)
     return int(_L.qldpc_crc32_words(w.ctypes.data_as(_up), int(n_bits)))
