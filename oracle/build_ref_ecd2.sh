@@ -41,6 +41,20 @@ second = s.index(arm)
 s = s[:second] + ("    case ALG_LDPC_CONTINUE_ROLES:\n    case ALG_LDPC_FLIP_ROLES:\n"
                   "      return ldpc_prepareAsQberInitiator(processBlock, (ALGORITHM_DECISION)in_head->algorithmEnum);\n") + s[second + len(arm):]
 open(p, "w").write(s)
+p = "subcomponents/priv_amp.c"
+s = open(p).read()
+loop = ("    for (i = 0; i < pb->finalKeyBits; i++) { /* go through all targetbits */\n"
+        "      m = 0;                                 /* initial word */\n"
+        "      for (j = 0; j < numwords; j++)\n"
+        "        m ^= (pb->mainBufPtr[j] & rnd_getPrngValue2_32(&pb->rngState));\n"
+        "      if (calcParity(m)) finalkey[wordIndex(i)] |= uint32AllZeroExceptAtN(i);\n"
+        "    }\n")
+assert s.count(loop) == 1
+s = s.replace(loop, "    if (getenv(\"ECD2_GPU_PA\")) {\n"
+                    "      if (qldpc_privamp(0, pb->mainBufPtr, pb->workbits, seed, pb->finalKeyBits, finalkey)) return 85;\n"
+                    "    } else {\n" + loop + "    }\n", 1)
+s = s.replace('#include "priv_amp.h"', '#include "priv_amp.h"\n#include "qldpc.h"\n#include <stdlib.h>', 1)
+open(p, "w").write(s)
 p = "ecd2.h"
 s = open(p).read()
 s = s.replace('    "Algorithm specific data ptr not null"\n};',

@@ -74,6 +74,50 @@ def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
 
 
 @pytest.mark.gpu
+def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
+    """4 epochs x 15 000 bits (the block of SURVEY.md section 4 / 6): LDPC reconciliation and the PA hash both on the GPU.
+    Alice hashes on her GPU, Bob on his: equal stream-7 files prove the GPU hash equals itself across processes AND,
+    through the CPU run below with the SAME daemons, that it is the reference's hash."""
+    binary = need("ecd2_ldpc")
+    a, b = epochs(5, 4, 15000, 0.02)
+    gpu = run_loopback(binary, tmp_path / "gpu", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"})
+    assert gpu["a_final"] is not None and (gpu["a_final"]["words"] == gpu["b_final"]["words"]).all()
+    # Bob on the GPU hash, Alice on the reference's CPU loop: the two final keys must still be identical
+    d = tmp_path / "mixed"
+    import subprocess, time, os
+    from ecd2_loopback import write_stream3, read_stream7
+    os.makedirs(d / "a" / "raw"); os.makedirs(d / "a" / "final"); os.makedirs(d / "b" / "raw"); os.makedirs(d / "b" / "final")
+    for f in ("a_cmd", "b_cmd", "a2b", "b2a", "a_q", "b_q"):
+        os.mkfifo(d / f)
+    for i, (x, y) in enumerate(zip(a, b)):
+        write_stream3(d / "a" / "raw" / ("%08x" % (0xb0b80000 + i)), 0xb0b80000 + i, x)
+        write_stream3(d / "b" / "raw" / ("%08x" % (0xb0b80000 + i)), 0xb0b80000 + i, y)
+
+    def start(side, send, recv, env):
+        e = dict(os.environ); e.update(env)
+        return subprocess.Popen([binary, "-c", side + "_cmd", "-s", send, "-r", recv, "-d", side + "/raw", "-f", side + "/final", "-l", side + "/notify",
+                                 "-q", side + "/resp", "-Q", side + "_q", "-V", "5"], cwd=d, env=e, stdout=open(d / (side + ".log"), "w"), stderr=subprocess.STDOUT)
+    pa = start("a", "a2b", "b2a", {"ECD2_LDPC": "1"})                          # CPU privacy amplification (reference loop)
+    pb = start("b", "b2a", "a2b", {"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"})     # GPU privacy amplification
+    try:
+        time.sleep(0.5)
+        with open(d / "a_cmd", "w") as f:
+            f.write("0xb0b80000 4\n")
+        t0 = time.time()
+        fa, fb = d / "a" / "final" / "b0b80000", d / "b" / "final" / "b0b80000"
+        while time.time() - t0 < 120 and not (fa.exists() and fb.exists() and fa.stat().st_size > 16 and fb.stat().st_size > 16):
+            time.sleep(0.2)
+        time.sleep(0.3)
+    finally:
+        for p in (pa, pb):
+            p.terminate()
+        for p in (pa, pb):
+            p.wait(10)
+    ka, kb = read_stream7(fa), read_stream7(fb)
+    assert ka["nbits"] == kb["nbits"] > 30000 and (ka["words"] == kb["words"]).all()
+
+
+@pytest.mark.gpu
 def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
     """same epochs through both daemons: both reconcile; LDPC leaks M+32 bits, cascade its parity count."""
     a, b = epochs(3, 4, 6000, 0.02)
