@@ -1,0 +1,46 @@
+"""GPU suite: the C host harness (qcrypto-ldpc_amd/host/qldpc_sim.c), i.e. BS/src/main.cpp's loop in C over the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "qcrypto-ldpc_amd", "host", "qldpc_sim")
+
+
+def rows(out):
+    r = []
+    for line in out.splitlines():
+        if line.startswith("#") or "|" not in line:
+            continue
+        f = [x.strip() for x in line.split("|")]
+        r.append(dict(ep=float(f[0]), fra=int(f[1]), be=int(f[2]), fe=int(f[3]), ber=float(f[4]), fer=float(f[5]), thr=float(f[6])))
+    return r
+
+
+def run(*args):
+    if not os.path.exists(SIM):
+        subprocess.check_call(["make", "-C", os.path.dirname(SIM)])
+    p = subprocess.run([SIM] + list(args), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+def test_rate08_threshold_matches_the_reference_tables():
+    """BS/data_dvb/data3 (DVB S2)/DVB_S2_N_64800_K_51840_CR_0.8.txt:31-36: rate 0.8 is clean up to 3 % and dead at
+    3.5 % and beyond (SPA); the DVB-like IRA code shows the same band."""
+    out = run("-N", "16384", "-K", "13107", "-r", "SPA", "-i", "50", "-f", "64", "-b", "64", "-s", "0.01:0.05:0.01")
+    r = {round(x["ep"], 2): x for x in rows(out)}
+    assert "Decoder_LDPC_BP_flooding_Update_rule_SPA" in out and "Code rate  (R) = 0.79" in out
+    assert r[0.01]["fe"] == 0 and r[0.02]["fe"] == 0 and r[0.01]["fra"] == 64
+    assert r[0.05]["fe"] == 64                         # far beyond the threshold: every frame fails
+    assert r[0.01]["thr"] > 0
+
+
+def test_alist_layered_minsum_runs():
+    out = run("-a", os.path.join(ROOT, "tests", "golden", "PEGReg504x1008.alist"), "-r", "NMS", "-p", "0.75", "-l", "-i", "20", "-f", "200", "-b", "100",
+              "-s", "0.02:0.02:0.01")
+    r = rows(out)
+    assert len(r) == 1 and r[0]["fra"] == 200 and r[0]["fe"] <= 2
+    assert "horizontal_layered" in out and "Info. bits (K) = 504" in out
