@@ -144,7 +144,10 @@ typedef struct qldpc_decoder_cfg {
     int device;          /* HIP device ordinal                                                   */
     int frames_per_lane; /* 0 = auto; 1, 2 or 4 frames per wavefront lane (64/128/256-frame groups) */
     int engine;          /* qldpc_engine: 0 = auto (edge-parallel for <= 8 frames when supported) */
-    int reserved[6];     /* must be zero                                                         */
+    int freeze_messages; /* FRAMES engine with enable_syndrome: 1 = a converged frame's messages are frozen bit-for-bit
+                            (lane-masked stores; qldpc_fetch_post_dev is then exact for every frame, ~15 % slower);
+                            0 = only its hard decisions / iteration count / success flag are frozen (default)      */
+    int reserved[5];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
 void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);

@@ -67,6 +67,7 @@ struct qldpc_decoder {
     int loaded, ran;
     int last_iters;
     int poll_every;
+    int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
     /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
     int engine, eW, eS, e_stride;
     size_t e_lds;
@@ -166,6 +167,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if (V == 0) V = 1;      /* measured on MI355X: 256-byte rows (V = 1) are 2-5 % faster than V = 2 / 4 at every batch size, and exit earlier */
     if (const char *e = getenv("QLDPC_FRAMES_PER_LANE")) { int x = atoi(e); if (x == 1 || x == 2 || x == 4) V = x; }
     d->V = V; d->FG = 64 * V; d->G = (cfg->max_frames + d->FG - 1) / d->FG;
+    d->freeze = cfg->freeze_messages ? 1 : 0;
+    if (const char *e = getenv("QLDPC_FREEZE")) d->freeze = atoi(e) ? 1 : 0;
     d->poll_every = d->G >= 8 ? 2 : 0;
     if (const char *e = getenv("QLDPC_POLL_EVERY")) d->poll_every = atoi(e);
 
@@ -378,7 +381,7 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_tr,
-                       (size_t)d->E * d->FG, d->d_done, r);
+                       (size_t)d->E * d->FG, d->d_done, r, d->freeze);
 }
 template <int V, int FAM>
 static void launch_cn_fam(qldpc_decoder *d, const bucket &b)
@@ -408,7 +411,7 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                       d->N, (size_t)d->E * d->FG, d->d_done, r);
+                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
 }
 template <int V, int FAM>
 static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
@@ -563,7 +566,7 @@ static int run_layered(qldpc_decoder *d)
                 for (auto &b : d->layer_buckets[(size_t)l]) { launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
-            hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N);
+            hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
             LAUNCHCHK();
             if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
             if ((rc = status_pass<V>(d, ite + 1))) return rc;
@@ -575,7 +578,7 @@ static int run_layered(qldpc_decoder *d)
         }
     }
     d->last_iters = std::min(ite, n_ite);
-    hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N);
+    hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
     LAUNCHCHK();
     return QLDPC_OK;
 }

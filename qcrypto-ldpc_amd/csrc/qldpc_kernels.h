@@ -200,7 +200,7 @@ template <int V, int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restrict__ v2c, float *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
-                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule)
+                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
     const int i = blockIdx.x * QK_WAVES + wave;
     if (i >= n_list) return;
     bool frozen[V];
-    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
+    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen) && freeze;
     const float *vin = v2c + (size_t)g * group_stride + lane * V;
     float *cout = c2v + (size_t)g * group_stride + lane * V;
 
@@ -387,12 +387,14 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restric
     for (int u = 0; u < UN; u++) {
 #pragma unroll
         for (int j = 0; j < V; j++) {
-            const u64 s = __ballot((qk_bits(tmp[u][j]) >> 31) != 0);
-            if (lane == 0) sgn[((size_t)g * N + vv[u]) * V + j] = s;
-            if constexpr (MODE == QK_VN_POST) {
-                const u64 h = __ballot(!(tmp[u][j] >= 0.0f));
-                if (lane == 0) hard[((size_t)g * N + vv[u]) * V + j] = h;
-            }
+            /* converged frames keep the ballots they converged with (their messages may go on evolving when
+             * the decoder is not in freeze mode: full-row stores are much cheaper than lane-masked ones) */
+            u64 s = __ballot((qk_bits(tmp[u][j]) >> 31) != 0);
+            u64 h = __ballot(!(tmp[u][j] >= 0.0f));
+            const size_t bi = ((size_t)g * N + vv[u]) * V + j;
+            const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * V + j];
+            if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
+            if (lane == 0) { sgn[bi] = s; hard[bi] = h; }
         }
         if constexpr (MODE == QK_VN_POST) {
             if (post_out) qk_store<V>(post_out + ((size_t)g * N + vv[u]) * FG + lane * V, tmp[u]);
@@ -412,7 +414,7 @@ template <int V, int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ post, float *__restrict__ msg,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
-                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule)
+                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
     const int i = blockIdx.x * QK_WAVES + wave;
     if (i >= n_list) return;
     bool frozen[V];
-    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen);
+    const bool any_frozen = qk_frozen<V>(done, g, lane, frozen) && freeze;
     float *pg = post + (size_t)g * N * FG + lane * V;
     float *mg = msg + (size_t)g * group_stride + lane * V;
 
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
 /* ballots of an explicit posterior array (layered schedule): sgn = signbit, hard = !(p >= 0) */
 template <int V>
 __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__restrict__ post, u64 *__restrict__ sgn,
-                                                              u64 *__restrict__ hard, int N)
+                                                              u64 *__restrict__ hard, int N, const u64 *__restrict__ done)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -496,9 +498,12 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
         qk_load<V>(p, post + ((size_t)g * N + v) * FG + lane * V);
 #pragma unroll
         for (int j = 0; j < V; j++) {
-            const u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
-            const u64 h = __ballot(!(p[j] >= 0.0f));
-            if (lane == 0) { sgn[((size_t)g * N + v) * V + j] = s; hard[((size_t)g * N + v) * V + j] = h; }
+            u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
+            u64 h = __ballot(!(p[j] >= 0.0f));
+            const size_t bi = ((size_t)g * N + v) * V + j;
+            const u64 dm = done[(size_t)g * V + j];      /* converged frames keep the ballots they converged with */
+            if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
+            if (lane == 0) { sgn[bi] = s; hard[bi] = h; }
         }
     }
 }

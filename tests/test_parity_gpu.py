@@ -72,7 +72,7 @@ def test_minsum_family_bit_exact(q, O, torch, peg, rule, param, sched, V):
         inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
         og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
     ref = O.decode(og, llr, rule, param, 25, sched, True, 1, n_threads=8)
-    dec = q.Decoder(code, 1008, 25, rule=rule, rule_param=param, n_frames=F, schedule=sched, frames_per_lane=V)
+    dec = q.Decoder(code, 1008, 25, rule=rule, rule_param=param, n_frames=F, schedule=sched, frames_per_lane=V, freeze_messages=True)
     hard, it, ok, post = staged(q, torch, dec, llr)
     assert (hard == ref["hard"]).all()
     assert (it == ref["iters"]).all()
@@ -122,7 +122,7 @@ def test_transcendental_rules_tolerance(q, O, torch, peg, rule, param, sched):
     F = 256
     llr = bsc_frames(np.random.default_rng(7), F, 1008, 0.07, 2.59)
     ref = O.decode(og, llr, rule, param, 20, sched, True, 1, n_threads=8)
-    dec = q.Decoder(code, 1008, 20, rule=rule, rule_param=param, n_frames=F, schedule=sched)
+    dec = q.Decoder(code, 1008, 20, rule=rule, rule_param=param, n_frames=F, schedule=sched, freeze_messages=True)
     hard, it, ok, post = staged(q, torch, dec, llr)
     same = (hard == ref["hard"]).all(axis=1)
     conv_ref = ref["synd_ok"] == 1
@@ -191,7 +191,7 @@ def test_qkd_frame_formation_from_packed_bits(q, O, torch, peg, kat):
     llr[:, par] = np.where(cw[:, par] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
     llr[:, par[:40]] = 0.0
     ref = O.decode(og, llr, "NMS", 0.75, 30, n_threads=8)
-    dec = q.Decoder(code, enc.K, 30, info_bits_pos=enc.info_bits_pos, rule="NMS", rule_param=0.75, n_frames=F)
+    dec = q.Decoder(code, enc.K, 30, info_bits_pos=enc.info_bits_pos, rule="NMS", rule_param=0.75, n_frames=F, freeze_messages=True)
     bits = torch.from_numpy(q.pack_bits(noisy).astype(np.int64).astype(np.uint32).view(np.int32)).cuda()
     dec.load_bits(bits, torch.from_numpy(mag).cuda(), torch.from_numpy(cls).cuda())
     dec.run()
@@ -251,7 +251,7 @@ def test_other_matrices(q, O, torch, gold, name, kind):
             inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
             g2 = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
         ref = O.decode(g2, llr, "OMS", 0.3, 15, sched, n_threads=8)
-        dec = q.Decoder(code, code.N, 15, rule="OMS", rule_param=0.3, n_frames=96, schedule=sched)
+        dec = q.Decoder(code, code.N, 15, rule="OMS", rule_param=0.3, n_frames=96, schedule=sched, freeze_messages=True)
         hard, it, ok, post = staged(q, torch, dec, llr)
         assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
         assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
@@ -264,7 +264,7 @@ def test_natural_layer_order_equals_plain_sequential_sweep(q, O, torch, gold):
     assert code.layer_order()[2]
     llr = bsc_frames(np.random.default_rng(4), 64, code.N, 0.04, 3.1)
     ref = O.decode(og, llr, "NMS", 0.8, 10, "hlayered", n_threads=8)
-    dec = q.Decoder(code, code.N, 10, rule="NMS", rule_param=0.8, n_frames=64, schedule="hlayered")
+    dec = q.Decoder(code, code.N, 10, rule="NMS", rule_param=0.8, n_frames=64, schedule="hlayered", freeze_messages=True)
     hard, it, _, post = staged(q, torch, dec, llr)
     assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
     assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
@@ -277,7 +277,7 @@ def test_high_degree_checks_use_the_generic_kernel(q, O, torch):
     og = O.Graph.from_edges(code.N, code.M, var, chk)
     llr = bsc_frames(np.random.default_rng(8), 64, code.N, 0.004, 5.5)
     ref = O.decode(og, llr, "NMS", 0.75, 12, n_threads=8)
-    dec = q.Decoder(code, code.N, 12, rule="NMS", rule_param=0.75, n_frames=64)
+    dec = q.Decoder(code, code.N, 12, rule="NMS", rule_param=0.75, n_frames=64, freeze_messages=True)
     hard, it, _, post = staged(q, torch, dec, llr)
     assert (hard == ref["hard"]).all() and (it == ref["iters"]).all()
     assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
@@ -305,3 +305,25 @@ def test_profile_hooks_report_algorithmic_bytes(q, torch, peg):
     assert st["cn_update"]["launches"] == 6 and st["vn_update"]["launches"] == 7       # FIRST + 5 + POST
     assert st["cn_update"]["alg_bytes"] == 6 * 2 * 3024 * 4 * 128
     assert st["cn_update"]["total_ms"] > 0
+
+
+@pytest.mark.parametrize("sched", ["flooding", "hlayered"])
+@pytest.mark.parametrize("V", [1, 4])
+def test_default_mode_freezes_decisions_not_messages(q, O, torch, peg, sched, V):
+    """freeze_messages = 0 (default, full-row stores): a converged frame's hard decision, iteration count and success
+    flag are still exactly the reference's; only its posterior keeps evolving with the rest of its 64-frame group."""
+    code, og = peg
+    F = 300
+    llr = bsc_frames(np.random.default_rng(77), F, 1008, 0.062, 2.65)
+    if sched == "hlayered":
+        order, _, _ = code.layer_order()
+        var, chk = og.edges()
+        inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+        og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    ref = O.decode(og, llr, "NMS", 0.75, 25, sched, True, 1, n_threads=8)
+    dec = q.Decoder(code, 1008, 25, rule="NMS", rule_param=0.75, n_frames=F, schedule=sched, frames_per_lane=V, engine="frames")
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    ran_all = it == dec.last_run_iterations            # frames that were never frozen keep exact posteriors
+    assert ran_all.any() and (post[ran_all].view(np.uint32) == ref["post"][ran_all].view(np.uint32)).all()
+    assert 0 < (ref["synd_ok"] == 0).sum() < F
