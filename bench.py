@@ -121,10 +121,17 @@ def main():
         log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libqldpc has no CPU fallback")
+    # one process per GPU; QLDPC_DIST_BACKEND=gloo lets several ranks rehearse the N > 1 path on a box with fewer GPUs
+    backend = os.environ.get("QLDPC_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -174,7 +181,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         if world > 1:
-            td = torch.tensor([dt], dtype=torch.float64, device=device)
+            td = torch.tensor([dt], dtype=torch.float64, device=comm_device)
             dist.all_reduce(td, op=dist.ReduceOp.MAX)
             dt = float(td.item())
         return dt
@@ -182,7 +189,7 @@ def main():
     def verdicts(dec):
         it, ok = dec.fetch_status()
         good = ((out == cw).all(dim=1)) & (ok == 1)
-        stats = torch.tensor([float(good.sum()), float(it.sum()), float(F)], dtype=torch.float64, device=device)
+        stats = torch.tensor([float(good.sum()), float(it.sum()), float(F)], dtype=torch.float64, device=comm_device)
         if world > 1:
             dist.all_reduce(stats)
         return stats.tolist()
@@ -243,6 +250,20 @@ def main():
         got = q.unpack_bits(out[:nref].cpu().numpy().view(np.uint32), N)
         cpu["gpu_matches_oracle_on_sample"] = bool((got == ref["hard"]).all())
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
+    # committed rocprofv3 --pmc summary of the SAME command (profiles/), used only when the workload matches.
+    traffic, traffic_src = None, None
+    if rank == 0:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_hbm_traffic.json")))
+            w = pmc["workload"]
+            fpl = args.frames_per_lane or 1
+            if (w["frames"], w["frames_per_lane"], w["N"], w["E"]) == (F, fpl, N, code.E):
+                traffic = pmc["kernels"]["qk_cn_flood<%d, 20, 0>" % fpl]["hbm_bytes_corrected"]
+                traffic_src = "profiles/r01_b_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
+        except Exception:
+            pass
+
     if rank == 0:
         line = {
             "metric": "reconciled_key_Mbit_s",
@@ -269,7 +290,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "qk_cn_flood (check-node update)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": cn_bytes, "avg_launch_ms": cn_avg_s * 1e3, "launches": cn["launches"],
                 "vn_update": {"achieved": vn_achieved, "frac": vn_achieved / HBM_PEAK_GBS,
                               "avg_pass_ms": vn["total_ms"] / vn["launches"], "passes": vn["launches"]},

@@ -32,6 +32,8 @@ def gather_blocks(local, total_frames, dst=0, group=None):
         pad = torch.zeros((cap - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        local = local.cpu()            # gloo rehearsal: stage through host memory
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
     dist.gather(local, bufs, dst=dst, group=group)
     if rank != dst:
