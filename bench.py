@@ -86,7 +86,7 @@ def cpu_baseline(code, frames_llr_fn, rule, param, n_ite, K):
     dt = time.time() - t0
     ok = int((r["synd_ok"] == 1).sum())
     return dict(value=ok * K / dt / 1e6, unit="Mbit/s", cores=cores, kind="port",
-                sample="%d frames of the same workload (flooding NMS %.2f, %d iterations fixed), %.1f s wall" % (n, param, n_ite, dt)), r, llr
+                sample="%d frames of the same workload (flooding %s %.2f, %d iterations fixed), %.1f s wall" % (n, rule, param, n_ite, dt)), r, llr
 
 
 def main():
@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--qber", type=float, default=0.02)
     ap.add_argument("--n-ite", type=int, default=50)
     ap.add_argument("--alpha", type=float, default=0.75)
+    ap.add_argument("--rule", default="NMS", help="update rule (the headline workload is NMS)")
     ap.add_argument("--frames-per-lane", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
@@ -153,7 +154,7 @@ def main():
         log("frames ready: %d per GPU (%.1f s), code N=%d K=%d M=%d E=%d" % (F, time.time() - t0, N, K, code.M, code.E))
 
     def make_decoder(enable_syndrome):
-        d = q.Decoder(code, K, args.n_ite, rule="NMS", rule_param=args.alpha, enable_syndrome=enable_syndrome,
+        d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
                       n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane)
         d.set_stream(torch.cuda.current_stream(device))
         return d
@@ -244,7 +245,7 @@ def main():
             llr[:, K:] = np.where(cwb[:, K:] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
             return llr
 
-        cpu, ref, ref_llr = cpu_baseline(code, llr_fn, "NMS", args.alpha, args.n_ite, K)
+        cpu, ref, ref_llr = cpu_baseline(code, llr_fn, args.rule, args.alpha, args.n_ite, K)
         # the same sample through the GPU must give the same words (cheap cross-check, not timed)
         nref = ref["hard"].shape[0]
         got = q.unpack_bits(out[:nref].cpu().numpy().view(np.uint32), N)
@@ -282,10 +283,10 @@ def main():
             "iterations_executed": fixed_iters,
             "frames_per_step": int(n_all),
             "config": {
-                "workload": "rate-%.1f N=%d IRA LDPC (K=%d, M=%d, E=%d), flooding NMS(%.2f), %d iterations fixed, QBER %.1f %%, "
-                            "%d frames per GPU, packed bits resident in HBM" % (K / N, N, K, code.M, code.E, args.alpha, args.n_ite,
+                "workload": "rate-%.1f N=%d IRA LDPC (K=%d, M=%d, E=%d), flooding %s(%.2f), %d iterations fixed, QBER %.1f %%, "
+                            "%d frames per GPU, packed bits resident in HBM" % (K / N, N, K, code.M, code.E, args.rule, args.alpha, args.n_ite,
                                                                                args.qber * 100, F),
-                "frames_per_gpu": F, "qber": args.qber, "n_ite": args.n_ite, "rule": "NMS", "alpha": args.alpha,
+                "frames_per_gpu": F, "qber": args.qber, "n_ite": args.n_ite, "rule": args.rule, "alpha": args.alpha,
                 "parallelism": "frame-sharded x%d, RCCL gather of decoded blocks only" % world,
             },
             "roofline": {

@@ -108,16 +108,29 @@ template <> struct qk_acc<QK_FAM_MS> {
     }
 };
 
+/*
+ * SPA transcendentals.  The float-LLR SPA variant is tolerance-class (FER / converged-word agreement, not
+ * bit-exactness: device and glibc tanh/atanh already differ in the last ulp), so the hardware exp / log /
+ * rcp units are used: tanh(a/2) = (1 - e^-a) / (1 + e^-a), 2 atanh(r) = ln((1 + r) / (1 - r)).  With the libm
+ * forms the check-node kernel is compute-bound at 3x the min-sum time; with these it is HBM-bound again.
+ */
+__device__ __forceinline__ float qk_tanh_half(float a) { const float e = __expf(-a); return __fdividef(1.0f - e, 1.0f + e); }
+__device__ __forceinline__ float qk_2atanh(float r) { return __logf(__fdividef(1.0f + r, 1.0f - r)); }
+
+/* messages enter the SPA fold as sign-carrying tanh(|x|/2) so the value is computed once per edge */
+template <int FAM> __device__ __forceinline__ float qk_prep(float x) { return x; }
+template <> __device__ __forceinline__ float qk_prep<QK_FAM_SPA>(float x) { return qk_withsign(qk_tanh_half(fabsf(x)), qk_bits(x)); }
+
 template <> struct qk_acc<QK_FAM_SPA> {
     uint32_t sign; float product;
     __device__ __forceinline__ void begin() { sign = 0; product = 1.0f; }
-    __device__ __forceinline__ void in(float x) { sign ^= qk_bits(x); product *= tanhf(fabsf(x) * 0.5f); }
+    __device__ __forceinline__ void in(float xp) { sign ^= qk_bits(xp); product *= fabsf(xp); }      /* xp = qk_prep(x) */
     __device__ __forceinline__ void finish(const qk_rule &) {}
-    __device__ __forceinline__ float out(float x, const qk_rule &) const
+    __device__ __forceinline__ float out(float xp, const qk_rule &) const
     {
-        float t = product / tanhf(fabsf(x) * 0.5f);
+        float t = __fdividef(product, fabsf(xp));
         t = (t < 1.0f) ? t : 1.0f - 1.1920928955078125e-07f;
-        return qk_withsign(2.0f * atanhf(t), sign ^ qk_bits(x));
+        return qk_withsign(qk_2atanh(t), sign ^ qk_bits(xp));
     }
 };
 
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
 #pragma unroll
-                for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[k][j], rule);
+                for (int j = 0; j < V; j++) { x[k][j] = qk_prep<FAM>(x[k][j]); qk_acc_in<FAM>(acc[j], x[k][j], rule); }
             }
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j].finish(rule);
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
             float x[V];
             qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
 #pragma unroll
-            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], x[j], rule);
+            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], qk_prep<FAM>(x[j]), rule);
         }
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j].finish(rule);
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
             const size_t off = (size_t)cn_tr[b + k] * FG;
             qk_load<V>(x, vin + off);
 #pragma unroll
-            for (int j = 0; j < V; j++) o[j] = acc[j].out(x[j], rule);
+            for (int j = 0; j < V; j++) o[j] = acc[j].out(qk_prep<FAM>(x[j]), rule);
             qk_store_masked<V>(cout + off, o, frozen, any_frozen);
         }
     }
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
 #pragma unroll
-                for (int j = 0; j < V; j++) { x[k][j] = x[k][j] - m[k][j]; qk_acc_in<FAM>(acc[j], x[k][j], rule); }
+                for (int j = 0; j < V; j++) { x[k][j] = x[k][j] - m[k][j]; qk_acc_in<FAM>(acc[j], qk_prep<FAM>(x[k][j]), rule); }
             }
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j].finish(rule);
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
             if (k < deg) {
                 float o[V], p[V];
 #pragma unroll
-                for (int j = 0; j < V; j++) { o[j] = acc[j].out(x[k][j], rule); p[j] = x[k][j] + o[j]; }
+                for (int j = 0; j < V; j++) { o[j] = acc[j].out(qk_prep<FAM>(x[k][j]), rule); p[j] = x[k][j] + o[j]; }
                 qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
                 qk_store_masked<V>(pg + (size_t)vn[k] * FG, p, frozen, any_frozen);
             }
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
             qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
             qk_load<V>(m, mg + (size_t)(b + k) * FG);
 #pragma unroll
-            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], p[j] - m[j], rule);
+            for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], qk_prep<FAM>(p[j] - m[j]), rule);
         }
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j].finish(rule);
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
             qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
             qk_load<V>(m, mg + (size_t)(b + k) * FG);
 #pragma unroll
-            for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(x, rule); p[j] = x + o[j]; }
+            for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(qk_prep<FAM>(x), rule); p[j] = x + o[j]; }
             qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
             qk_store_masked<V>(pg + (size_t)cn_var[b + k] * FG, p, frozen, any_frozen);
         }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
                 s_val[off + s] = qk_withsign((fabsf(x) == m1) ? cst1 : cst2, sg ^ qk_bits(x));
             }
         } else {   /* SPA: the product is reduced as a tree, so it is tolerance-class (not order-exact) */
-            const float t = act ? tanhf(fabsf(x) * 0.5f) : 1.0f;
+            const float t = act ? qk_tanh_half(fabsf(x)) : 1.0f;
             float prod = t;
             uint32_t sg = act ? (qk_bits(x) & 0x80000000u) : 0u;
 #pragma unroll
@@ -112,9 +112,9 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
                 par ^= __shfl_xor(par, o);
             }
             if (act && !syndrome_only) {
-                float r = prod / t;
+                float r = __fdividef(prod, t);
                 r = (r < 1.0f) ? r : 1.0f - 1.1920928955078125e-07f;
-                s_val[off + s] = qk_withsign(2.0f * atanhf(r), sg ^ qk_bits(x));
+                s_val[off + s] = qk_withsign(qk_2atanh(r), sg ^ qk_bits(x));
             }
         }
         any_unsat |= par;
