@@ -76,6 +76,9 @@ struct qldpc_decoder {
     int *e_unsat, *e_done_at;
     int *h_done;
     hipEvent_t e_ev[2];
+    int use_graphs, graph_frames;
+    hipStream_t cap_stream;
+    std::vector<hipGraphExec_t> e_graphs;   /* one per chunk of poll_every iterations */
     /* profiling */
     int prof_on;
     std::vector<prof_rec> prof_pending;
@@ -148,6 +151,8 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
     if (d->h_done) (void)hipHostFree(d->h_done);
+    for (auto &g : d->e_graphs) if (g) (void)hipGraphExecDestroy(g);
+    if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
     if (d->e_ev[0]) (void)hipEventDestroy(d->e_ev[0]);
     if (d->e_ev[1]) (void)hipEventDestroy(d->e_ev[1]);
     if (d->h_active) (void)hipHostFree(d->h_active);
@@ -225,6 +230,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         HIPCHK(hipEventCreateWithFlags(&d->e_ev[1], hipEventDisableTiming));
         d->poll_every = 4;
         if (const char *e = getenv("QLDPC_POLL_EVERY")) d->poll_every = atoi(e);
+        d->use_graphs = 1; d->graph_frames = -1;
+        if (const char *e = getenv("QLDPC_NO_GRAPH")) d->use_graphs = atoi(e) ? 0 : 1;
         return QLDPC_OK;
     }
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
@@ -637,31 +644,93 @@ static int edge_vn(qldpc_decoder *d, int ite, int check, int force, float *post_
     return QLDPC_OK;
 }
 
+/* launches of iterations [ite0, ite1) on d->stream (+ the decoder-reset prologue in front of iteration 0) */
+static int edge_emit(qldpc_decoder *d, int ite0, int ite1)
+{
+    int rc;
+    const int n_ite = d->cfg.n_ite, synd = d->cfg.enable_syndrome;
+    if (ite0 == 0) {
+        hipLaunchKernelGGL(qe_init, dim3((unsigned)d->n_frames), dim3(64), 0, d->stream, d->e_unsat, d->e_stride, d->e_done_at, d->n_frames);
+        LAUNCHCHK();
+        if ((rc = edge_vn<QK_VN_FIRST>(d, 0, 0, 0, nullptr, 0))) return rc;
+    }
+    for (int ite = ite0; ite < ite1; ite++) {
+        if ((rc = edge_cn(d, d->e_sgn, ite, 0))) return rc;
+        if (ite == n_ite - 1) rc = edge_vn<QK_VN_POST>(d, ite, synd, 0, nullptr, ite & 1);
+        else rc = edge_vn<QK_VN_NORMAL>(d, ite, synd, 0, nullptr, ite & 1);
+        if (rc) return rc;
+    }
+    if (ite1 == n_ite + 1) return edge_cn(d, d->e_hard, n_ite + 1, 1);   /* epilogue chunk: success flag of the final hard decisions */
+    return QLDPC_OK;
+}
+
+/*
+ * The launch-bound inner loop as hipGraphs: one instantiated graph per chunk of `poll_every` iterations
+ * (kernel arguments differ per iteration, so each chunk has its own graph), captured once per frame count
+ * on a private stream and replayed on the caller's stream.  The host only polls between chunks.
+ */
+static int edge_chunk_graph(qldpc_decoder *d, int chunk, int ite0, int ite1, hipGraphExec_t *out)
+{
+    if (d->graph_frames != d->n_frames) {
+        for (auto &g : d->e_graphs) if (g) (void)hipGraphExecDestroy(g);
+        d->e_graphs.clear();
+        d->graph_frames = d->n_frames;
+    }
+    if ((int)d->e_graphs.size() <= chunk) d->e_graphs.resize((size_t)chunk + 1, nullptr);
+    if (!d->e_graphs[(size_t)chunk]) {
+        if (!d->cap_stream) HIPCHK(hipStreamCreateWithFlags(&d->cap_stream, hipStreamNonBlocking));
+        hipStream_t user = d->stream;
+        d->stream = d->cap_stream;
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamBeginCapture(d->cap_stream, hipStreamCaptureModeRelaxed);
+        int rc = QLDPC_EHIP;
+        if (e == hipSuccess) {
+            rc = edge_emit(d, ite0, ite1);
+            e = hipStreamEndCapture(d->cap_stream, &g);
+        }
+        d->stream = user;
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) { qldpc_set_error("graph capture: %s", hipGetErrorString(e)); return QLDPC_EHIP; }
+        hipGraphExec_t x = nullptr;
+        e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) { qldpc_set_error("graph instantiate: %s", hipGetErrorString(e)); return QLDPC_EHIP; }
+        d->e_graphs[(size_t)chunk] = x;
+    }
+    *out = d->e_graphs[(size_t)chunk];
+    return QLDPC_OK;
+}
+
 static int run_edges(qldpc_decoder *d)
 {
     int rc;
     const int n_ite = d->cfg.n_ite, F = d->n_frames, synd = d->cfg.enable_syndrome;
-    hipLaunchKernelGGL(qe_init, dim3((unsigned)F), dim3(64), 0, d->stream, d->e_unsat, d->e_stride, d->e_done_at, F);
-    LAUNCHCHK();
-    if ((rc = edge_vn<QK_VN_FIRST>(d, 0, 0, 0, nullptr, 0))) return rc;
-    int ite = 0, pending = -1, flip = 0;
-    for (; ite < n_ite; ite++) {
-        if ((rc = edge_cn(d, d->e_sgn, ite, 0))) return rc;
-        if (ite == n_ite - 1) { if ((rc = edge_vn<QK_VN_POST>(d, ite, synd, 0, nullptr, ite & 1))) return rc; ite++; break; }
-        if ((rc = edge_vn<QK_VN_NORMAL>(d, ite, synd, 0, nullptr, ite & 1))) return rc;
-        if (synd && d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {
-            /* look-ahead polling: wait for the snapshot queued one poll ago, so the GPU always has work queued */
+    const int P = (synd && d->poll_every > 0) ? d->poll_every : n_ite;
+    const bool graphs = d->use_graphs && !d->prof_on;
+    int ite = 0, pending = -1, flip = 0, chunk = 0;
+    bool stopped = false;
+    while (ite < n_ite) {
+        const int ite1 = std::min(n_ite, ite + P);
+        if (graphs) {
+            hipGraphExec_t x;
+            if ((rc = edge_chunk_graph(d, chunk, ite, ite1, &x))) return rc;
+            HIPCHK(hipGraphLaunch(x, d->stream));
+        } else if ((rc = edge_emit(d, ite, ite1))) return rc;
+        ite = ite1; chunk++;
+        if (synd && ite < n_ite) {
+            /* look-ahead polling: wait for the snapshot queued one chunk ago, so the GPU always has work queued */
             if (pending >= 0) {
                 HIPCHK(hipEventSynchronize(d->e_ev[pending]));
                 bool all = true;
                 for (int f = 0; f < F; f++) all = all && d->h_done[(size_t)pending * F + f] >= 0;
-                if (all) { ite++; break; }
+                if (all) { stopped = true; break; }
             }
             HIPCHK(hipMemcpyAsync(d->h_done + (size_t)flip * F, d->e_done_at, sizeof(int) * (size_t)F, hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipEventRecord(d->e_ev[flip], d->stream));
             pending = flip; flip ^= 1;
         }
     }
+    (void)stopped;
     d->last_iters = ite;
     /* success flag: syndrome of the final hard decisions into the last slot */
     return edge_cn(d, d->e_hard, n_ite + 1, 1);

@@ -76,7 +76,7 @@ __device__ __forceinline__ float qk_ams_min(int rule, float a, float b)
 {
     const float m = qk_min(a, b);
     if (rule == 5) return m;
-    if (rule == 7) return m + logf(1.0f + expf(-(a + b))) - logf(1.0f + expf(-fabsf(a - b)));
+    if (rule == 7) return m + __logf(1.0f + __expf(-(a + b))) - __logf(1.0f + __expf(-fabsf(a - b)));   /* tolerance class: hardware exp/log */
     const float r = m + qk_corr_l2(a + b) - qk_corr_l2(a - b);
     return r > 0.0f ? r : 0.0f;
 }
@@ -138,8 +138,8 @@ template <> struct qk_acc<QK_FAM_LSPA> {
     uint32_t sign; float sum;
     __device__ __forceinline__ static float term(float x)
     {
-        const float t = tanhf(fabsf(x) * 0.5f);
-        return (t != 0.0f) ? logf(t) : 1.175494351e-38f;
+        const float t = qk_tanh_half(fabsf(x));
+        return (t != 0.0f) ? __logf(t) : 1.175494351e-38f;
     }
     __device__ __forceinline__ void begin() { sign = 0; sum = 0.0f; }
     __device__ __forceinline__ void in(float x) { sign ^= qk_bits(x); sum += term(x); }
@@ -147,8 +147,9 @@ template <> struct qk_acc<QK_FAM_LSPA> {
     __device__ __forceinline__ float out(float x, const qk_rule &) const
     {
         float t = sum - term(x);
-        t = (t != 0.0f) ? expf(t) : 1.0f - 1.1920928955078125e-07f;
-        return qk_withsign(2.0f * atanhf(t), sign ^ qk_bits(x));
+        t = (t != 0.0f) ? __expf(t) : 1.0f - 1.1920928955078125e-07f;
+        t = (t < 1.0f) ? t : 1.0f - 1.1920928955078125e-07f;      /* keep ln((1+t)/(1-t)) finite when rounding gives 1 */
+        return qk_withsign(qk_2atanh(t), sign ^ qk_bits(x));
     }
 };
 
