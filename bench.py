@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--frames-per-lane", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-message-storage variant leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -153,9 +154,9 @@ def main():
     if rank == 0:
         log("frames ready: %d per GPU (%.1f s), code N=%d K=%d M=%d E=%d" % (F, time.time() - t0, N, K, code.M, code.E))
 
-    def make_decoder(enable_syndrome):
+    def make_decoder(enable_syndrome, msg_dtype="f32"):
         d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
-                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane)
+                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype)
         d.set_stream(torch.cuda.current_stream(device))
         return d
 
@@ -230,6 +231,27 @@ def main():
         del dec
         torch.cuda.empty_cache()
 
+    # ---- variant (NOT the headline): messages stored as binary16, fp32 arithmetic ----------------------------
+    # FER-tolerance class against the AFF3CT float build; bit-exact against the oracle with the same rounding.
+    fp16 = None
+    if not args.no_fp16:
+        fp16 = {}
+        for name, synd in (("fixed", False), ("early_exit", True)):
+            dec = make_decoder(synd, "f16")
+            dec.profile(True)
+            step(dec)
+            dec.profile_clear()
+            dth = timed(dec, max(1, args.steps), 0)
+            ks = {s["name"]: s for s in dec.profile_read()}
+            dec.profile(False)
+            gh, ith, nh = verdicts(dec)
+            cnh = ks["cn_update"]
+            fp16[name] = dict(value=gh * K * max(1, args.steps) / dth / 1e6, unit="Mbit/s", fer=1.0 - gh / nh, avg_iterations=ith / nh,
+                              ms_per_step=dth / max(1, args.steps) * 1e3,
+                              cn_update_GBs=(cnh["alg_bytes"] / cnh["launches"]) / (cnh["total_ms"] / cnh["launches"] * 1e-3) / 1e9)
+            del dec
+            torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -300,6 +322,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "early_exit": early,
+            "fp16_messages": fp16,
             "reference_context": {"aff3ct_spa_1thread_debug_Mbit_s": 0.241, "cascade_daemon_Mbit_s": 0.3},
         }
         print(json.dumps(line), flush=True)

@@ -147,7 +147,10 @@ typedef struct qldpc_decoder_cfg {
     int freeze_messages; /* FRAMES engine with enable_syndrome: 1 = a converged frame's messages are frozen bit-for-bit
                             (lane-masked stores; qldpc_fetch_post_dev is then exact for every frame, ~15 % slower);
                             0 = only its hard decisions / iteration count / success flag are frozen (default)      */
-    int reserved[5];     /* must be zero                                                         */
+    int msg_dtype;       /* 0 = fp32 messages (the AFF3CT float build, bit-exact class); 1 = messages rounded to
+                            binary16 in HBM, fp32 arithmetic (half the bytes per iteration; FER-tolerance class against
+                            AFF3CT, bit-exact against the oracle run with the same rounding; FRAMES engine, flooding) */
+    int reserved[4];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
 void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);

@@ -123,7 +123,7 @@ class Graph:
 
 
 def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", enable_syndrome=True,
-           syndrome_depth=1, n_threads=1):
+           syndrome_depth=1, n_threads=1, msg_fp16=False):
     """decode_siho on llr[n_frames, N]; returns dict(post, hard, iters, synd_ok)."""
     llr = np.ascontiguousarray(llr, dtype=np.float32)
     if llr.ndim == 1:
@@ -134,7 +134,7 @@ def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", ena
     hard = np.empty((F, N), np.int32)
     iters = np.empty(F, np.int32)
     ok = np.empty(F, np.int32)
-    rc = lib().orc_decode(graph._h, SCHEDULES[schedule], RULES[rule], float(param), int(n_ite), int(enable_syndrome),
+    rc = lib().orc_decode(graph._h, SCHEDULES[schedule], RULES[rule] | (0x100 if msg_fp16 else 0), float(param), int(n_ite), int(enable_syndrome),
                           int(syndrome_depth), _fp(llr), F, _fp(post), _ip(hard), _ip(iters), _ip(ok), int(n_threads))
     if rc != 0:
         raise RuntimeError("orc_decode failed: %d" % rc)

@@ -309,6 +309,39 @@ static int syndrome_is_zero(const orc_graph *g, const float *post)
     return 1;
 }
 
+/* ------------------------------------------------------------- fp16 message storage ------ */
+
+/* round-to-nearest-even float -> IEEE binary16 -> float, in integer arithmetic (what the GPU's __float2half_rn /
+ * __half2float pair does); used when the decoder under test stores its messages as binary16 */
+static int g_msg_fp16 = 0;
+#pragma omp threadprivate(g_msg_fp16)
+static float rne16(float f)
+{
+    union { float f; unsigned u; } v = { f };
+    const unsigned sign = v.u & 0x80000000u;
+    unsigned a = v.u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return f;                                  /* inf / nan */
+    if (a >= 0x477ff000u) { v.u = sign | 0x7f800000u; return v.f; }  /* >= 65520 rounds to inf */
+    if (a < 0x33000001u) { v.u = sign; return v.f; }                 /* < 2^-25 (or = 2^-25, tie to even 0) rounds to 0 */
+    unsigned h;
+    if (a < 0x38800000u) {                                           /* binary16 subnormal: quantum 2^-24 */
+        const int shift = 126 - (int)(a >> 23);                      /* 14 .. 24 */
+        const unsigned m = (a & 0x7fffffu) | 0x800000u;
+        const unsigned q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        h = q + ((rem > half) || (rem == half && (q & 1u)));
+        /* back to float: h * 2^-24 */
+        v.f = (float)h * 5.9604644775390625e-08f;
+        v.u |= sign;
+        return v.f;
+    }
+    const unsigned rem = a & 0x1fffu, q = a >> 13;
+    a = (q + ((rem > 0x1000u) || (rem == 0x1000u && (q & 1u)))) << 13;
+    v.u = sign | a;
+    return v.f;
+}
+static inline float stq(float x) { return g_msg_fp16 ? rne16(x) : x; }
+float orc_round_fp16(float x) { return rne16(x); }      /* exported so the tests can pin it against numpy's float16 */
+
 /* ------------------------------------------------------------- flooding ------------------ */
 
 /*
@@ -333,13 +366,13 @@ static int decode_flooding(const orc_graph *g, int rule, float param, int n_ite,
             float sum = 0.0f;
             for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
             const float tmp = Y[v] + sum;
-            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) v2c[e] = tmp - c2v[e];
+            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) v2c[e] = stq(tmp - c2v[e]);
         }
         for (int c = 0; c < M; c++) {
             const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
             for (int i = 0; i < deg; i++) in[i] = v2c[g->transpose[b + i]];
             cn_update(rule, param, deg, in, out, scratch);
-            for (int i = 0; i < deg; i++) c2v[g->transpose[b + i]] = out[i];
+            for (int i = 0; i < deg; i++) c2v[g->transpose[b + i]] = stq(out[i]);
         }
         if (enable_syndrome && ite != n_ite - 1) {
             for (int v = 0; v < N; v++) {
@@ -401,7 +434,10 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
                float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
 {
     if (!g || !Y_N || n_frames < 0 || n_ite < 0) return -1;
+    const int fp16 = (rule & ORC_MSG_FP16) != 0;      /* flag bit: messages stored as binary16 (flooding only) */
+    rule &= ~ORC_MSG_FP16;
     if (rule < ORC_RULE_MS || rule > ORC_RULE_AMS_MINSTAR) return -2;
+    if (fp16 && schedule != ORC_SCHED_FLOODING) return -4;
     if (schedule != ORC_SCHED_FLOODING && schedule != ORC_SCHED_HLAYERED) return -3;
     if (syndrome_depth < 1) syndrome_depth = 1;
     const int N = g->N, E = g->E;
@@ -416,6 +452,7 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
         float *in = (float *)malloc(sizeof(float) * (size_t)(g->max_dc + 1) * 3);
         float *out = in + g->max_dc + 1, *scratch = out + g->max_dc + 1;
         int *hd = (int *)malloc(sizeof(int) * (size_t)N);
+        g_msg_fp16 = fp16;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif

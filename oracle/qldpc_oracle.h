@@ -39,6 +39,10 @@ enum {
     ORC_RULE_AMS_MINSTAR = 7     /* MIN = min_star                      */
 };
 
+/* OR into `rule`: store var_to_chk / chk_to_var rounded to IEEE binary16 (round-to-nearest-even), arithmetic in
+ * fp32 -- mirrors the product's fp16 message-storage mode; not an AFF3CT configuration of the reference harness */
+#define ORC_MSG_FP16 0x100
+
 /* Schedules (AFF3CT module::Decoder_LDPC_BP_{flooding,horizontal_layered}) */
 enum { ORC_SCHED_FLOODING = 0, ORC_SCHED_HLAYERED = 1 };
 

@@ -67,6 +67,7 @@ struct qldpc_decoder {
     int loaded, ran;
     int last_iters;
     int poll_every;
+    int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
     int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
     /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
     int engine, eW, eS, e_stride;
@@ -169,7 +170,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if (cfg->device < 0 || cfg->device >= ndev) { qldpc_set_error("device %d out of range (%d visible)", cfg->device, ndev); return QLDPC_ENODEV; }
     HIPCHK(hipSetDevice(cfg->device));
     int V = cfg->frames_per_lane;
-    if (V == 0) V = 1;      /* measured on MI355X: 256-byte rows (V = 1) are 2-5 % faster than V = 2 / 4 at every batch size, and exit earlier */
+    if (V == 0) V = (cfg->msg_dtype == 1) ? 2 : 1;      /* fp16 storage: 2 frames per lane keep the rows at 256 bytes; measured on MI355X: 256-byte rows (V = 1) are 2-5 % faster than V = 2 / 4 at every batch size, and exit earlier */
     if (const char *e = getenv("QLDPC_FRAMES_PER_LANE")) { int x = atoi(e); if (x == 1 || x == 2 || x == 4) V = x; }
     d->V = V; d->FG = 64 * V; d->G = (cfg->max_frames + d->FG - 1) / d->FG;
     d->freeze = cfg->freeze_messages ? 1 : 0;
@@ -210,6 +211,12 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         }
         if (eng == QLDPC_ENGINE_AUTO) eng = (edge_ok && cfg->max_frames <= 8) ? QLDPC_ENGINE_EDGES : QLDPC_ENGINE_FRAMES;
         d->engine = eng;
+        d->msg_half = cfg->msg_dtype == 1;
+        if (const char *e = getenv("QLDPC_MSG_HALF")) d->msg_half = atoi(e) ? 1 : 0;
+        if (d->msg_half && (eng != QLDPC_ENGINE_FRAMES || cfg->schedule != QLDPC_SCHED_FLOODING)) {
+            if (cfg->engine == QLDPC_ENGINE_AUTO && cfg->schedule == QLDPC_SCHED_FLOODING) d->engine = QLDPC_ENGINE_FRAMES;
+            else { qldpc_set_error("fp16 message storage is implemented for the flooding schedule on the FRAMES engine"); return QLDPC_EUNSUPPORTED; }
+        }
     }
     if (d->engine == QLDPC_ENGINE_EDGES) {
         const size_t F = (size_t)cfg->max_frames;
@@ -249,8 +256,9 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
     if ((rc = dev_alloc(d, &d->d_llr, G * d->N * FG))) return rc;
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
-        if ((rc = dev_alloc(d, &d->d_a, G * d->E * FG))) return rc;
-        if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
+        const size_t elems = d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG;      /* floats of storage */
+        if ((rc = dev_alloc(d, &d->d_a, elems))) return rc;
+        if ((rc = dev_alloc(d, &d->d_b, elems))) return rc;
     } else {
         if ((rc = dev_alloc(d, &d->d_a, G * d->N * FG))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
@@ -390,8 +398,12 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
 {
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
-    hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_tr,
-                       (size_t)d->E * d->FG, d->d_done, r, d->freeze);
+    if (d->msg_half)
+        hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
+                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
+    else
+        hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, float>), grid, dim3(QK_THREADS), 0, d->stream, (const float *)d->d_a, d->d_b, b.d_list, b.n,
+                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
 }
 template <int V, int FAM>
 static void launch_cn_fam(qldpc_decoder *d, const bucket &b)
@@ -445,26 +457,19 @@ static void launch_layer(qldpc_decoder *d, const bucket &b)
     }
 }
 
+template <int V, int CAP, int UNX, int MODE, typename MT>
+static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
+{
+    dim3 grid((unsigned)grid_x(b.n, UNX), (unsigned)d->G);
+    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
+                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
+}
 template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
 {
-    constexpr int UN = (CAP > 0 && CAP <= 4) ? 4 : (CAP > 0 ? 2 : 2);
-    static const int un_env = getenv("QLDPC_VN_UN") ? atoi(getenv("QLDPC_VN_UN")) : 0;      /* tuning knob */
-    if (CAP == 4 && MODE == QK_VN_NORMAL && (un_env == 2 || un_env == 8)) {
-        if (un_env == 2) {
-            dim3 grid((unsigned)grid_x(b.n, 2), (unsigned)d->G);
-            hipLaunchKernelGGL((qk_vn_flood<V, CAP, 2, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
-                               b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
-        } else {
-            dim3 grid((unsigned)grid_x(b.n, 8), (unsigned)d->G);
-            hipLaunchKernelGGL((qk_vn_flood<V, CAP, 8, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
-                               b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
-        }
-        return;
-    }
-    dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
-    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, d->d_b, d->d_llr, d->d_a, d->d_sgn, d->d_hard, post_out,
-                       b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
+    constexpr int UN = (CAP > 0 && CAP <= 4) ? 4 : 2;
+    if (d->msg_half) launch_vn_k<V, CAP, UN, MODE, __half>(d, b, post_out);
+    else launch_vn_k<V, CAP, UN, MODE, float>(d, b, post_out);
 }
 template <int V, int MODE>
 static void launch_vn(qldpc_decoder *d, const bucket &b, float *post_out)
@@ -478,12 +483,13 @@ static void launch_vn(qldpc_decoder *d, const bucket &b, float *post_out)
 }
 
 /* algorithmic bytes: only live (non-padding) frames are counted */
-static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * 4.0 * d->n_frames; }
+static double msg_b(const qldpc_decoder *d) { return d->msg_half ? 2.0 : 4.0; }
+static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * msg_b(d) * d->n_frames; }
 static double bytes_vn(const qldpc_decoder *d, int mode)
 {
-    if (mode == QK_VN_FIRST) return ((double)d->E + d->N) * 4.0 * d->n_frames;
-    if (mode == QK_VN_POST) return ((double)d->E + d->N) * 4.0 * d->n_frames;
-    return (2.0 * d->E + d->N) * 4.0 * d->n_frames;
+    if (mode == QK_VN_FIRST) return ((double)d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
+    if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
+    return (2.0 * d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
 }
 static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * 4.0 * d->n_frames; }
 

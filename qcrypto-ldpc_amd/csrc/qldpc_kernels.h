@@ -17,6 +17,7 @@
 #define QLDPC_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 typedef unsigned long long u64;
@@ -65,6 +66,42 @@ template <int V> __device__ __forceinline__ void qk_store_masked(float *p, const
 #pragma unroll
     for (int j = 0; j < V; j++) if (!frozen[j]) p[j] = d[j];
 }
+
+/*
+ * fp16 message storage (qldpc_decoder_cfg.msg_dtype = 1): messages are ROUNDED TO NEAREST EVEN to binary16 when
+ * stored and widened exactly when loaded; every sum / min / product is still fp32.  Halves the HBM bytes per
+ * iteration.  Not the AFF3CT float build any more (FER-tolerance class against it), but bit-exact against the
+ * oracle run with the same rounding.
+ */
+template <int V> __device__ __forceinline__ void qk_load(float (&d)[V], const __half *p)
+{
+    if constexpr (V == 1) d[0] = __half2float(p[0]);
+    else if constexpr (V == 2) { const __half2 t = *reinterpret_cast<const __half2 *>(p); d[0] = __low2float(t); d[1] = __high2float(t); }
+    else {
+        const uint2 t = *reinterpret_cast<const uint2 *>(p);
+        const __half2 a = *reinterpret_cast<const __half2 *>(&t.x), b = *reinterpret_cast<const __half2 *>(&t.y);
+        d[0] = __low2float(a); d[1] = __high2float(a); d[2] = __low2float(b); d[3] = __high2float(b);
+    }
+}
+template <int V> __device__ __forceinline__ void qk_store(__half *p, const float (&d)[V])
+{
+    if constexpr (V == 1) p[0] = __float2half_rn(d[0]);
+    else if constexpr (V == 2) *reinterpret_cast<__half2 *>(p) = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1]));
+    else {
+        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1])), b = __halves2half2(__float2half_rn(d[2]), __float2half_rn(d[3]));
+        uint2 t;
+        t.x = *reinterpret_cast<const uint32_t *>(&a); t.y = *reinterpret_cast<const uint32_t *>(&b);
+        *reinterpret_cast<uint2 *>(p) = t;
+    }
+}
+template <int V> __device__ __forceinline__ void qk_store_masked(__half *p, const float (&d)[V], const bool (&frozen)[V], bool any_frozen)
+{
+    if (!any_frozen) { qk_store<V>(p, d); return; }
+#pragma unroll
+    for (int j = 0; j < V; j++) if (!frozen[j]) p[j] = __float2half_rn(d[j]);
+}
+__device__ __forceinline__ void qk_put(float *p, float v) { *p = v; }
+__device__ __forceinline__ void qk_put(__half *p, float v) { *p = __float2half_rn(v); }
 
 __device__ __forceinline__ uint32_t qk_bits(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float qk_withsign(float mag, uint32_t signbit) { return __uint_as_float((__float_as_uint(mag) & 0x7fffffffu) | (signbit & 0x80000000u)); }
@@ -210,8 +247,8 @@ template <int V> __device__ __forceinline__ bool qk_frozen(const u64 *__restrict
  * DCMAX > 0: messages stay in registers (checks in `list` have degree <= DCMAX).
  * DCMAX == 0: any degree, second pass re-reads the rows (they are L2-hot).
  */
-template <int V, int DCMAX, int FAM>
-__global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restrict__ v2c, float *__restrict__ c2v,
+template <int V, int DCMAX, int FAM, typename MT>
+__global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__ v2c, MT *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                                           size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze)
@@ -225,8 +262,8 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
     if (i >= n_list) return;
     bool frozen[V];
     const bool any_frozen = qk_frozen<V>(done, g, lane, frozen) && freeze;
-    const float *vin = v2c + (size_t)g * group_stride + lane * V;
-    float *cout = c2v + (size_t)g * group_stride + lane * V;
+    const MT *vin = v2c + (size_t)g * group_stride + lane * V;
+    MT *cout = c2v + (size_t)g * group_stride + lane * V;
 
     const int c = list[i];
     const int b = cn_ptr[c];
@@ -265,7 +302,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
                 if (k < deg) {
 #pragma unroll
                     for (int j = 0; j < V; j++)
-                        if (!frozen[j]) cout[(size_t)slot[k] * FG + j] = acc[j].out(x[k][j], rule);
+                        if (!frozen[j]) qk_put(&cout[(size_t)slot[k] * FG + j], acc[j].out(x[k][j], rule));
                 }
         }
     } else {
@@ -301,9 +338,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const float *__restric
  * check_syndrome_soft tests) and hard = !(tmp >= 0) (what decode_siho outputs).
  * One wavefront handles UN list entries with every row load issued before the first use.
  */
-template <int V, int DVMAX, int UN, int MODE>
-__global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restrict__ c2v, const float *__restrict__ llr,
-                                                          float *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
+template <int V, int DVMAX, int UN, int MODE, typename MT>
+__global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__ c2v, const float *__restrict__ llr,
+                                                          MT *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride,
@@ -314,8 +351,8 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const float *__restric
     if (MODE != QK_VN_POST && qk_group_done<V>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float *cin = c2v + (size_t)g * group_stride + lane * V;
-    float *vout = v2c + (size_t)g * group_stride + lane * V;
+    const MT *cin = c2v + (size_t)g * group_stride + lane * V;
+    MT *vout = v2c + (size_t)g * group_stride + lane * V;
     const float *yin = llr + (size_t)g * N * FG + lane * V;
     const int i0 = (blockIdx.x * QK_WAVES + wave) * UN;
     if (i0 >= n_list) return;

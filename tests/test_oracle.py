@@ -102,3 +102,25 @@ def test_threads_do_not_change_results(O, peg):
     a = O.decode(peg, llr, "NMS", 0.75, 20, n_threads=1)
     b = O.decode(peg, llr, "NMS", 0.75, 20, n_threads=4)
     assert (a["hard"] == b["hard"]).all() and (a["iters"] == b["iters"]).all() and (a["post"] == b["post"]).all()
+
+
+def test_fp16_rounding_emulation_matches_numpy_float16(O):
+    import ctypes as C
+    L = O.lib()
+    L.orc_round_fp16.restype = C.c_float
+    L.orc_round_fp16.argtypes = [C.c_float]
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.normal(0, 30, 4000), rng.normal(0, 1e-3, 1000), rng.normal(0, 1e-6, 1000), rng.normal(0, 1e-8, 1000),
+                           [0.0, -0.0, 65504, 65519.9, 65520, 7e4, -7e4, 6.1e-5, 5.96e-8, 2.9802322e-8, 2.99e-8, 1e-10, 8.9e-8]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        exp = vals.astype(np.float16).astype(np.float32)
+    got = np.array([L.orc_round_fp16(float(v)) for v in vals], np.float32)
+    assert (got.view(np.uint32) == exp.view(np.uint32)).all()
+
+
+def test_fp16_message_storage_changes_little(O, peg):
+    rng = np.random.default_rng(2)
+    llr = np.where(rng.random((32, 1008)) < 0.05, -2.9, 2.9).astype(np.float32)
+    a = O.decode(peg, llr, "NMS", 0.75, 20)
+    b = O.decode(peg, llr, "NMS", 0.75, 20, msg_fp16=True)
+    assert (a["synd_ok"] == b["synd_ok"]).mean() > 0.9 and np.abs(a["iters"] - b["iters"]).max() <= 3

@@ -328,3 +328,45 @@ def test_default_mode_freezes_decisions_not_messages(q, O, torch, peg, sched, V)
     ran_all = it == dec.last_run_iterations            # frames that were never frozen keep exact posteriors
     assert ran_all.any() and (post[ran_all].view(np.uint32) == ref["post"][ran_all].view(np.uint32)).all()
     assert 0 < (ref["synd_ok"] == 0).sum() < F
+
+
+@pytest.mark.parametrize("V", [1, 2, 4])
+@pytest.mark.parametrize("rule,param", [("NMS", 0.75), ("OMS", 0.35), ("MS", 0.0)])
+def test_fp16_message_storage_is_bit_exact_against_the_rounding_oracle(q, O, torch, peg, rule, param, V):
+    """msg_dtype = f16: messages rounded to binary16 (RNE) when stored, fp32 arithmetic.  Against the oracle run with the
+    same rounding: identical hard decisions, iteration counts, success flags and posteriors."""
+    code, og = peg
+    F = 200
+    llr = bsc_frames(np.random.default_rng(31 + V), F, 1008, 0.06 if rule != "MS" else 0.045, 2.7)
+    ref = O.decode(og, llr, rule, param, 25, "flooding", True, 1, n_threads=8, msg_fp16=True)
+    dec = q.Decoder(code, 1008, 25, rule=rule, rule_param=param, n_frames=F, frames_per_lane=V, msg_dtype="f16", freeze_messages=True)
+    hard, it, ok, post = staged(q, torch, dec, llr)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+    ref32 = O.decode(og, llr, rule, param, 25, "flooding", True, 1, n_threads=8)
+    assert abs((ref["synd_ok"] == 0).mean() - (ref32["synd_ok"] == 0).mean()) < 0.05       # FER tolerance vs fp32: 5 points on 200 frames
+
+
+def test_fp16_message_storage_full_size_fer_and_requests(q, O, torch):
+    code = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
+    enc = q.Encoder(code, "IRA")
+    rng = np.random.default_rng(8)
+    F = 128
+    cw = enc.encode(rng.integers(0, 2, (F, enc.K)))
+    mag = np.float32(q.bsc_llr(0.02))
+    y = cw.copy()
+    y[:, :enc.K] ^= rng.random((F, enc.K)) < 0.02
+    llr = np.where(y == 1, -mag, mag).astype(np.float32)
+    llr[:, enc.K:] = np.where(cw[:, enc.K:] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    ref = O.decode(og, llr[:32], "NMS", 0.75, 50, n_threads=8, msg_fp16=True)
+    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, n_frames=F, msg_dtype="f16")
+    hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
+    assert (hard[:32] == ref["hard"]).all() and (it[:32] == ref["iters"]).all()
+    assert (ok == 1).all() and (hard == cw).all()                                        # FER 0/128 at QBER 2 %, as fp32
+    assert dec.device_bytes < 0.62 * q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, n_frames=F, frames_per_lane=2).device_bytes
+    for kw in (dict(schedule="hlayered"), dict(engine="edges")):
+        with pytest.raises(q.QldpcError) as e:
+            q.Decoder(code, enc.K, 5, rule="NMS", n_frames=4, msg_dtype="f16", **kw)
+        assert e.value.status == -7
