@@ -67,6 +67,7 @@ struct qldpc_decoder {
     int loaded, ran;
     int last_iters;
     int poll_every;
+    float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
     int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
     /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
@@ -149,7 +150,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
-    (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active);
+    (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
     if (d->h_done) (void)hipHostFree(d->h_done);
     for (auto &g : d->e_graphs) if (g) (void)hipGraphExecDestroy(g);
@@ -948,9 +949,12 @@ extern "C" int qldpc_decode_siho(qldpc_decoder *d, const float *Y_N, int *V_K, i
     int rc = check_frames(d, n_frames, "qldpc_decode_siho");
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
-    float *din = nullptr; int *dout = nullptr;
-    HIPCHK(hipMalloc((void **)&din, sizeof(float) * (size_t)n_frames * d->N));
-    if (hipMalloc((void **)&dout, sizeof(int) * (size_t)n_frames * d->K) != hipSuccess) { (void)hipFree(din); qldpc_set_error("decode_siho: hipMalloc failed"); return QLDPC_ENOMEM; }
+    /* staging buffers for the host-pointer call live with the decoder (sized for max_frames on first use) */
+    if (!d->h_in) {
+        if ((rc = dev_alloc(d, &d->h_in, (size_t)d->cfg.max_frames * d->N))) return rc;
+        if ((rc = dev_alloc(d, &d->h_out, (size_t)d->cfg.max_frames * d->K))) return rc;
+    }
+    float *din = d->h_in; int *dout = d->h_out;
     rc = QLDPC_OK;
     if (hipMemcpyAsync(din, Y_N, sizeof(float) * (size_t)n_frames * d->N, hipMemcpyHostToDevice, d->stream) != hipSuccess) rc = QLDPC_EHIP;
     if (!rc) rc = qldpc_load_llr_dev(d, din, n_frames);
@@ -958,7 +962,6 @@ extern "C" int qldpc_decode_siho(qldpc_decoder *d, const float *Y_N, int *V_K, i
     if (!rc) rc = qldpc_fetch_info_dev(d, dout);
     if (!rc && hipMemcpyAsync(V_K, dout, sizeof(int) * (size_t)n_frames * d->K, hipMemcpyDeviceToHost, d->stream) != hipSuccess) rc = QLDPC_EHIP;
     if (hipStreamSynchronize(d->stream) != hipSuccess && !rc) rc = QLDPC_EHIP;
-    (void)hipFree(din); (void)hipFree(dout);
     if (rc == QLDPC_EHIP) qldpc_set_error("decode_siho: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
     return rc;
 }
