@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--n-ite", type=int, default=50)
     ap.add_argument("--alpha", type=float, default=0.75)
     ap.add_argument("--rule", default="NMS", help="update rule (the headline workload is NMS)")
+    ap.add_argument("--schedule", default="flooding", help="flooding (headline) | hlayered (experiment)")
     ap.add_argument("--frames-per-lane", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
@@ -156,7 +157,7 @@ def main():
 
     def make_decoder(enable_syndrome, msg_dtype="f32"):
         d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
-                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype)
+                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype, schedule=args.schedule)
         d.set_stream(torch.cuda.current_stream(device))
         return d
 
@@ -208,6 +209,9 @@ def main():
     good, it_sum, n_all = verdicts(dec)
     value = good * K * args.steps / dt / 1e6
     fer = 1.0 - good / n_all
+    if args.schedule != "flooding":          # experiment mode: one kernel family, no CPU / fp16 legs
+        kstats["cn_update"] = kstats["vn_update"] = kstats["layer_update"]
+        args.no_fp16 = args.no_cpu = True
     cn = kstats["cn_update"]
     vn = kstats["vn_update"]
     cn_avg_s = cn["total_ms"] / cn["launches"] * 1e-3
