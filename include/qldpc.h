@@ -244,7 +244,9 @@ typedef struct qldpc_recon_cfg {
     int key_quantum;       /* 1024 (multiple of 32)                                              */
     int max_blocks;        /* blocks decoded concurrently by qldpc_recon_decode_batch            */
     uint64_t seed;         /* IRA construction seed shared by both sides (7)                     */
-    int reserved[8];
+    int schedule;          /* qldpc_schedule of Bob's decoder: FLOODING (default) or HLAYERED (about half the
+                              iterations; batches only -- the one-block edge engine is flooding)           */
+    int reserved[7];
 } qldpc_recon_cfg;
 
 /* Travels in the parity packet (all fields uint32, little-endian like every ecd2 header). */

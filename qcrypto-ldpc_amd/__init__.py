@@ -445,7 +445,7 @@ def unpack_bits(words, n):
 class ReconCfg(C.Structure):
     _fields_ = [("device", C.c_int), ("efficiency", C.c_float), ("n_rates", C.c_int), ("rates", C.c_float * 8),
                 ("n_ite", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("key_quantum", C.c_int),
-                ("max_blocks", C.c_int), ("seed", C.c_uint64), ("reserved", C.c_int * 8)]
+                ("max_blocks", C.c_int), ("seed", C.c_uint64), ("schedule", C.c_int), ("reserved", C.c_int * 7)]
 
 
 class ReconMsg(C.Structure):
@@ -486,7 +486,7 @@ class Recon:
     """One side's reconciliation engine: what an ecd2 LDPC handler calls (qber_estim.c:337-340,420-423)."""
 
     def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=50, rule="NMS", rule_param=0.75,
-                 key_quantum=1024, max_blocks=1, seed=7):
+                 key_quantum=1024, max_blocks=1, seed=7, schedule="flooding"):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
         cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
@@ -494,6 +494,7 @@ class Recon:
             cfg.rates[i] = float(r)
         cfg.n_ite, cfg.rule, cfg.rule_param = int(n_ite), RULES[rule], float(rule_param)
         cfg.key_quantum, cfg.max_blocks, cfg.seed = int(key_quantum), int(max_blocks), int(seed)
+        cfg.schedule = SCHEDULES[schedule]
         h = _vp()
         _chk(_L.qldpc_recon_create(C.byref(cfg), C.byref(h)), "Recon")
         self._h = h

@@ -166,7 +166,7 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     if (!rc) {
         qldpc_decoder_cfg dc;
         qldpc_decoder_cfg_default(&dc);
-        dc.schedule = QLDPC_SCHED_FLOODING; dc.rule = r->cfg.rule; dc.rule_param = r->cfg.rule_param; dc.n_ite = r->cfg.n_ite;
+        dc.schedule = r->cfg.schedule == QLDPC_SCHED_HLAYERED ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING; dc.rule = r->cfg.rule; dc.rule_param = r->cfg.rule_param; dc.n_ite = r->cfg.n_ite;
         dc.enable_syndrome = 1; dc.syndrome_depth = 1; dc.max_frames = B; dc.device = r->cfg.device;
         rc = qldpc_decoder_create(e.code, K, nullptr, &dc, &e.dec);
     }

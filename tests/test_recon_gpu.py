@@ -108,3 +108,16 @@ def test_crc32_known_answer(q):
     junk = q.pack_bits(bits).copy()
     junk[-1] |= 0x00FFFFFF                                      # garbage past n_bits must not matter
     assert q.crc32_words(junk, 72) == zlib.crc32(data + b"\0\0\0")
+
+
+def test_layered_sessions_reconcile_the_same_blocks(q):
+    rng = np.random.default_rng(9)
+    r = q.Recon(max_blocks=12, schedule="hlayered")
+    key_bits = 20000
+    A, B, msgs, pars = [], [], [], []
+    for i in range(12):
+        a, b, _ = block(q, rng, key_bits, 0.025)
+        m, par = r.encode(a, key_bits, 0.025)
+        A.append(a); B.append(b); msgs.append(m); pars.append(par)
+    st, fixed, co, it = r.decode_batch(np.stack(B), key_bits, np.full(12, 0.025, np.float32), msgs, np.stack(pars))
+    assert (st == 0).all() and (fixed == np.stack(A)).all() and it.max() <= 12

@@ -23,7 +23,8 @@ alice = rng.integers(0, 2, (EPOCHS, KEY_BITS)).astype(np.uint8)
 bob = alice ^ (rng.random((EPOCHS, KEY_BITS)) < qbers[:, None])
 aw, bw = q.pack_bits(alice), q.pack_bits(bob)
 
-ra, rb = q.Recon(max_blocks=1), q.Recon(max_blocks=BATCH)
+SCHED = os.environ.get("SCHEDULE", "flooding")
+ra, rb = q.Recon(max_blocks=1), q.Recon(max_blocks=BATCH, schedule=SCHED)
 plans = [ra.plan(KEY_BITS, p) for p in qbers]
 groups = {}
 for i, m in enumerate(plans):
@@ -54,7 +55,7 @@ for key, idx in groups.items():
         assert (fixed[good] == aw[j][good]).all()
 dt = time.perf_counter() - t0
 leak = sum(plans[i].code_m + 32 for i in range(EPOCHS) if ok[i])
-print("config 3 stream: %d epochs x %d bits, QBER U[0.5%%, 6%%], batch <= %d" % (EPOCHS, KEY_BITS, BATCH))
+print("config 3 stream: %d epochs x %d bits, QBER U[0.5%%, 6%%], batch <= %d, Bob decodes %s" % (EPOCHS, KEY_BITS, BATCH, SCHED))
 for key, idx in sorted(groups.items()):
     print("  rate %.1f (K %d, M %d): %3d epochs, %3d reconciled, mean iterations %.1f" % (ra.rates[key[0]], key[1], key[2], len(idx), int(ok[idx].sum()), iters[idx].mean()))
 print("  Bob decode: %.1f ms total -> %.1f Mbit/s of sifted key, FER %.3f, leaked fraction %.3f | Alice encode %.1f ms (%.2f ms/epoch)" % (
