@@ -117,6 +117,13 @@ int qldpc_code_from_edges(int N, int M, int E, const int *var, const int *chk, q
  * socket shuffle.  (N=65536,K=52429,hi_frac=.125,dv_hi=11,dv_lo=3,seed=7) is BASELINE config 2.
  */
 int qldpc_code_ira(int N, int K, float hi_frac, int dv_hi, int dv_lo, uint64_t seed, qldpc_code **out);
+/*
+ * The same profile with the information part built by progressive edge growth (what the reference's
+ * ldpc_examples/improved-peg.py:136-195 / psd-peg.py set out to do): each new edge goes to a lowest-degree
+ * check not reached from its variable node within `depth` check levels, so no cycle shorter than
+ * 2 (depth + 1) is closed while avoidable (depth 2: no 4-cycles).  Deterministic in (profile, depth, seed).
+ */
+int qldpc_code_ira_peg(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out);
 void qldpc_code_free(qldpc_code *code);
 int qldpc_code_n(const qldpc_code *code);
 int qldpc_code_m(const qldpc_code *code);

@@ -88,6 +88,7 @@ _sig("qldpc_code_from_alist", C.c_int, [C.c_char_p, C.POINTER(_vp)])
 _sig("qldpc_code_from_qc", C.c_int, [C.c_char_p, C.POINTER(_vp)])
 _sig("qldpc_code_from_edges", C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, C.POINTER(_vp)])
 _sig("qldpc_code_ira", C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint64, C.POINTER(_vp)])
+_sig("qldpc_code_ira_peg", C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(_vp)])
 _sig("qldpc_code_free", None, [_vp])
 for _n in ("n", "m", "e", "max_cn_degree", "max_vn_degree", "is_ira", "layer_count"):
     _sig("qldpc_code_" + _n, C.c_int, [_vp])
@@ -209,6 +210,13 @@ class Code:
     def ira(cls, N, K, hi_frac=0.125, dv_hi=11, dv_lo=3, seed=7):
         h = _vp()
         _chk(_L.qldpc_code_ira(int(N), int(K), float(hi_frac), int(dv_hi), int(dv_lo), int(seed), C.byref(h)), "Code.ira")
+        return cls(h.value)
+
+    @classmethod
+    def ira_peg(cls, N, K, hi_frac=0.125, dv_hi=11, dv_lo=3, depth=2, seed=7):
+        """IRA profile with a progressive-edge-growth information part (depth 2: no 4-cycles)."""
+        h = _vp()
+        _chk(_L.qldpc_code_ira_peg(int(N), int(K), float(hi_frac), int(dv_hi), int(dv_lo), int(depth), int(seed), C.byref(h)), "Code.ira_peg")
         return cls(h.value)
 
     def edges(self):

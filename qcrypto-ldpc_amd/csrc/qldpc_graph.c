@@ -489,3 +489,138 @@ int qldpc_gf2_systematic(const qldpc_code *g, int **pivots_out, int **free_out, 
     *pivots_out = piv; *free_out = fr; *A_out = A; *wpr_out = wpr;
     return r;
 }
+
+/* ------------------------------------------------------------------ PEG construction ---------- */
+
+/*
+ * Progressive-edge-growth construction of the information part of a DVB-like IRA code
+ * (what EC/ldpc_examples/improved-peg.py:136-195 and psd-peg.py set out to do):
+ * variable nodes are connected one edge at a time, low degrees first; each new edge goes to a check of
+ * the lowest current degree among those NOT reached from the variable node within `depth` check levels
+ * of the graph built so far, so no cycle shorter than 2*(depth+1) is closed while that is possible
+ * (depth 2 = no 4-cycles).  The dual-diagonal parity chain is in place from the start.  Ties are broken
+ * by a seeded PRNG: both ends of a link build the same code from (N, K, profile, depth, seed).
+ */
+typedef struct { int *a; int n, cap; } ivec;
+static int ivec_push(ivec *v, int x)
+{
+    if (v->n == v->cap) {
+        int nc = v->cap ? v->cap * 2 : 8;
+        int *na = (int *)realloc(v->a, sizeof(int) * (size_t)nc);
+        if (!na) return -1;
+        v->a = na; v->cap = nc;
+    }
+    v->a[v->n++] = x;
+    return 0;
+}
+
+int qldpc_code_ira_peg(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out)
+{
+    if (!out) return QLDPC_EINVAL;
+    *out = NULL;
+    const int M = N - K;
+    if (N <= 0 || K <= 0 || M <= 1 || dv_hi < dv_lo || dv_lo < 1 || hi_frac < 0.0f || hi_frac > 1.0f || depth < 1 || depth > 4 || dv_hi > M) {
+        qldpc_set_error("code_ira_peg: bad parameters N=%d K=%d depth=%d", N, K, depth);
+        return QLDPC_EINVAL;
+    }
+    const int n_hi = (int)floor((double)hi_frac * (double)K);
+    int rc = QLDPC_ENOMEM;
+    ivec *cvn = (ivec *)calloc((size_t)M, sizeof(ivec));     /* VNs of each check (info + parity) */
+    ivec *vcn = (ivec *)calloc((size_t)N, sizeof(ivec));     /* checks of each VN */
+    int *cdeg = (int *)calloc((size_t)M, sizeof(int));       /* info degree of each check */
+    int *stamp_c = (int *)calloc((size_t)M, sizeof(int)), *stamp_v = (int *)calloc((size_t)N, sizeof(int)), *lvl_c = (int *)calloc((size_t)M, sizeof(int));
+    int *fr = (int *)malloc(sizeof(int) * (size_t)N), *fr2 = (int *)malloc(sizeof(int) * (size_t)N);
+    ivec *bucket = NULL; int *bpos = (int *)malloc(sizeof(int) * (size_t)M);
+    int maxdeg_cap = 0;
+    long T = (long)n_hi * dv_hi + (long)(K - n_hi) * dv_lo;
+    int *var = NULL, *chk = NULL;
+    if (!cvn || !vcn || !cdeg || !stamp_c || !stamp_v || !lvl_c || !fr || !fr2 || !bpos) goto done;
+    maxdeg_cap = (int)(T / M) + 64;
+    bucket = (ivec *)calloc((size_t)maxdeg_cap + 1, sizeof(ivec));
+    if (!bucket) goto done;
+    for (int c = 0; c < M; c++) {                              /* parity chain: VN K+c on checks c and c+1 */
+        if (ivec_push(&cvn[c], K + c) || ivec_push(&vcn[K + c], c)) goto done;
+        if (c + 1 < M && (ivec_push(&cvn[c + 1], K + c) || ivec_push(&vcn[K + c], c + 1))) goto done;
+        bpos[c] = bucket[0].n;
+        if (ivec_push(&bucket[0], c)) goto done;
+    }
+    {
+        xoshiro rng; uint64_t sm = seed;
+        for (int i = 0; i < 4; i++) rng.s[i] = splitmix64(&sm);
+        int tick = 0, min_d = 0;
+        for (int pass = 0; pass < 2; pass++) {                 /* low degrees first (PEG order) */
+            const int v_lo = pass == 0 ? n_hi : 0, v_hi = pass == 0 ? K : n_hi, dv = pass == 0 ? dv_lo : dv_hi;
+            for (int v = v_lo; v < v_hi; v++) {
+                for (int k = 0; k < dv; k++) {
+                    /* breadth-first expansion from v: record the level at which each check is first reached */
+                    tick++;
+                    int nf = 1; fr[0] = v; stamp_v[v] = tick;
+                    long cum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int lvl = 0; lvl < depth && nf > 0; lvl++) {
+                        int nf2 = 0;
+                        long newly = 0;
+                        for (int i = 0; i < nf; i++) {
+                            const ivec *cl = &vcn[fr[i]];
+                            for (int j = 0; j < cl->n; j++) {
+                                const int c = cl->a[j];
+                                if (stamp_c[c] == tick) continue;
+                                stamp_c[c] = tick; lvl_c[c] = lvl; newly++;
+                                const ivec *vl = &cvn[c];
+                                for (int t2 = 0; t2 < vl->n; t2++) { const int u = vl->a[t2]; if (stamp_v[u] != tick) { stamp_v[u] = tick; fr2[nf2++] = u; } }
+                            }
+                        }
+                        cum[lvl] = (lvl ? cum[lvl - 1] : 0) + newly;
+                        for (int l2 = lvl + 1; l2 < 8; l2++) cum[l2] = cum[lvl];
+                        { int *tmp = fr; fr = fr2; fr2 = tmp; nf = nf2; }
+                    }
+                    /* exclude every level that still leaves a candidate: the deepest l with cum[l] < M (level 0 always) */
+                    int excl = 0;
+                    for (int l2 = 1; l2 < depth; l2++) if (cum[l2] < M) excl = l2;
+                    /* lowest-degree check that is not excluded; random start inside the bucket */
+                    int pick = -1;
+                    for (int d = min_d; d <= maxdeg_cap && pick < 0; d++) {
+                        const ivec *b = &bucket[d];
+                        if (b->n == 0) { if (d == min_d) min_d++; continue; }
+                        const int start = (int)xo_below(&rng, (uint64_t)b->n);
+                        for (int i = 0; i < b->n; i++) {
+                            const int c = b->a[(start + i) % b->n];
+                            if (stamp_c[c] != tick || lvl_c[c] > excl) { pick = c; break; }
+                        }
+                    }
+                    if (pick < 0) { qldpc_set_error("code_ira_peg: no admissible check for VN %d", v); rc = QLDPC_EINVAL; goto done; }
+                    /* move the check one bucket up and record the edge */
+                    {
+                        const int d = cdeg[pick];
+                        ivec *b = &bucket[d];
+                        const int last = b->a[b->n - 1];
+                        b->a[bpos[pick]] = last; bpos[last] = bpos[pick]; b->n--;
+                        if (d + 1 > maxdeg_cap) { qldpc_set_error("code_ira_peg: degree overflow"); rc = QLDPC_EINVAL; goto done; }
+                        bpos[pick] = bucket[d + 1].n;
+                        if (ivec_push(&bucket[d + 1], pick)) goto done;
+                        cdeg[pick] = d + 1;
+                    }
+                    if (ivec_push(&cvn[pick], v) || ivec_push(&vcn[v], pick)) goto done;
+                }
+            }
+        }
+    }
+    {
+        long E = 0;
+        for (int c = 0; c < M; c++) E += cvn[c].n;
+        var = (int *)malloc(sizeof(int) * (size_t)E); chk = (int *)malloc(sizeof(int) * (size_t)E);
+        if (!var || !chk) goto done;
+        long e = 0;
+        for (int c = 0; c < M; c++) {
+            int *row = cvn[c].a; const int n = cvn[c].n;
+            for (int i = 1; i < n; i++) { int x = row[i], j = i - 1; while (j >= 0 && row[j] > x) { row[j + 1] = row[j]; j--; } row[j + 1] = x; }
+            for (int i = 0; i < n; i++, e++) { var[e] = row[i]; chk[e] = c; }
+        }
+        rc = qldpc_code_from_edges(N, M, (int)E, var, chk, out);
+    }
+done:
+    if (cvn) for (int c = 0; c < M; c++) free(cvn[c].a);
+    if (vcn) for (int v = 0; v < N; v++) free(vcn[v].a);
+    if (bucket) for (int d = 0; d <= maxdeg_cap; d++) free(bucket[d].a);
+    free(cvn); free(vcn); free(cdeg); free(stamp_c); free(stamp_v); free(lvl_c); free(fr); free(fr2); free(bucket); free(bpos); free(var); free(chk);
+    return rc;
+}

@@ -10,6 +10,7 @@
  *
  * usage: qldpc_sim [-N n] [-K k | -a alist | -q qc] [-r MS|OMS|NMS|SPA|LSPA|AMS_MIN|AMS_MINSTAR_L2|AMS_MINSTAR] [-p param]
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
+ *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
  */
 #include <math.h>
 #include <stdint.h>
@@ -46,12 +47,12 @@ static int die(const char *what, int rc)
 
 int main(int argc, char **argv)
 {
-    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, opt;
+    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, opt;
     const char *alist = NULL, *qc = NULL, *rule_name = "NMS";
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:ln")) != -1) {
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:ln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -64,6 +65,7 @@ int main(int argc, char **argv)
         case 'b': batch = atoi(optarg); break;
         case 's': if (sscanf(optarg, "%lf:%lf:%lf", &ber_min, &ber_max, &ber_step) != 3) { fprintf(stderr, "-s min:max:step\n"); return 2; } break;
         case 'S': seed = strtoull(optarg, NULL, 0); break;
+        case 'P': peg = atoi(optarg); break;
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -75,7 +77,7 @@ int main(int argc, char **argv)
     if (rule < 0) { fprintf(stderr, "unknown rule %s\n", rule_name); return 2; }
 
     qldpc_code *H = NULL;
-    int rc = alist ? qldpc_code_from_alist(alist, &H) : qc ? qldpc_code_from_qc(qc, &H) : qldpc_code_ira(N, K, 0.125f, 11, 3, 7, &H);
+    int rc = alist ? qldpc_code_from_alist(alist, &H) : qc ? qldpc_code_from_qc(qc, &H) : peg ? qldpc_code_ira_peg(N, K, 0.125f, 11, 3, peg, 7, &H) : qldpc_code_ira(N, K, 0.125f, 11, 3, 7, &H);
     if (rc) return die("code", rc);
     N = qldpc_code_n(H);
     qldpc_encoder *enc = NULL;

@@ -171,3 +171,35 @@ def test_decoder_argument_checks_come_before_the_device(q, gold):
             q.Decoder(c, args["K"], args["n_ite"], n_frames=args["n_frames"], syndrome_depth=args["syndrome_depth"],
                       frames_per_lane=args["frames_per_lane"])
         assert e.value.status == status, kw
+
+
+def test_peg_construction_has_no_4_cycles_and_keeps_the_ira_shape(q):
+    """qldpc_code_ira_peg: depth 2 closes no 4-cycle, check degrees stay concentrated,
+    the parity part is still the dual diagonal, and both ends build the same code from the same seed."""
+    from collections import defaultdict
+    N, K = 4096, 3277
+
+    def shared_pairs(code):
+        var, chk = code.edges()
+        rows = defaultdict(list)
+        for v, c in zip(var.tolist(), chk.tolist()):
+            rows[c].append(v)
+        seen = defaultdict(int)
+        for vs in rows.values():
+            for i in range(len(vs)):
+                for j in range(i + 1, len(vs)):
+                    seen[(min(vs[i], vs[j]), max(vs[i], vs[j]))] += 1
+        return sum(1 for n in seen.values() if n >= 2)
+
+    peg, rnd = q.Code.ira_peg(N, K, depth=2, seed=7), q.Code.ira(N, K, seed=7)
+    assert shared_pairs(peg) == 0 and shared_pairs(rnd) > 100
+    assert peg.is_ira and peg.N == N and peg.M == N - K
+    var, chk = peg.edges()
+    dv, dc = np.bincount(var, minlength=N), np.bincount(chk, minlength=N - K)
+    assert (dv[:409] == 11).all() and (dv[409:K] == 3).all() and dc.max() - dc.min() <= 3
+    v2, c2 = q.Code.ira_peg(N, K, depth=2, seed=7).edges()
+    assert (v2 == var).all() and (c2 == chk).all()
+    v3, _ = q.Code.ira_peg(N, K, depth=2, seed=8).edges()
+    assert (v3 != var).any()
+    with pytest.raises(q.QldpcError):
+        q.Code.ira_peg(N, K, depth=9)
