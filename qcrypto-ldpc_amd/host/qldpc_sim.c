@@ -11,6 +11,7 @@
  * usage: qldpc_sim [-N n] [-K k | -a alist | -q qc] [-r MS|OMS|NMS|SPA|LSPA|AMS_MIN|AMS_MINSTAR_L2|AMS_MINSTAR] [-p param]
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
  *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
+ *                  [-e f (puncture parity bits to reach the rate min_cr(ber, f); random pattern re-drawn per batch, main.cpp:321-333,359-362)]
  */
 #include <math.h>
 #include <stdint.h>
@@ -48,11 +49,12 @@ static int die(const char *what, int rc)
 int main(int argc, char **argv)
 {
     int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, opt;
+    double target_eff = 0.0;      /* > 0: puncture parity bits up to min_cr(ber, f), as BS/src/main.cpp:235-333 does */
     const char *alist = NULL, *qc = NULL, *rule_name = "NMS";
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:ln")) != -1) {
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:ln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -66,6 +68,7 @@ int main(int argc, char **argv)
         case 's': if (sscanf(optarg, "%lf:%lf:%lf", &ber_min, &ber_max, &ber_step) != 3) { fprintf(stderr, "-s min:max:step\n"); return 2; } break;
         case 'S': seed = strtoull(optarg, NULL, 0); break;
         case 'P': peg = atoi(optarg); break;
+        case 'e': target_eff = atof(optarg); break;
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -106,8 +109,20 @@ int main(int argc, char **argv)
     int *dec_bits = (int *)malloc(sizeof(int) * (size_t)batch * K);
     float *llr = (float *)malloc(sizeof(float) * (size_t)batch * N);
     rng_state = seed;
+    int *par_pos = (int *)malloc(sizeof(int) * (size_t)(N - K + 1));
+    int n_par = 0;
+    for (int v = 0; v < N; v++) if (!is_info[v]) par_pos[n_par++] = v;
     for (double ber = ber_min; ber <= ber_max + 1e-12; ber += ber_step) {
         const float L = qldpc_bsc_llr((float)ber);
+        /* parity_bits_to_punct(INFO_B, TTL_B, GOAL_CR) with GOAL_CR = min_cr(QBER, EFF)   (BS/src/main.cpp:29,34,280) */
+        int n_punct = 0;
+        if (target_eff > 0.0) {
+            n_punct = qldpc_parity_bits_to_punct(N, K, qldpc_min_code_rate((float)ber, (float)target_eff));
+            if (n_punct < 0) { printf("# ber %.4f: mother code rate already above the goal, nothing to puncture\n", ber); n_punct = 0; }
+            if (n_punct > n_par) n_punct = n_par;
+            printf("# ber %.4f: puncturing %d of %d parity bits -> rate %.4f, efficiency f = %.3f\n", ber, n_punct, n_par, (double)K / (N - n_punct),
+                   ((double)(n_par - n_punct) / K) / (double)qldpc_binary_entropy((float)ber));
+        }
         long fra = 0, be = 0, fe = 0;
         double t_dec = 0.0;
         while (fra < frames) {
@@ -120,6 +135,10 @@ int main(int argc, char **argv)
                     if (is_info[v]) { const int y = x ^ (rng_unit() < ber); llr[(size_t)f * N + v] = y ? -L : L; }      /* BSC + demodulate */
                     else llr[(size_t)f * N + v] = x ? -QLDPC_CONFIRMED_BIT_LLR : QLDPC_CONFIRMED_BIT_LLR;                /* disclosed parity */
                 }
+            if (n_punct > 0) {      /* new random pattern per batch: partial Fisher-Yates over the parity positions */
+                for (int i = 0; i < n_punct; i++) { const int j = i + (int)(rng_next() % (uint64_t)(n_par - i)); const int t = par_pos[i]; par_pos[i] = par_pos[j]; par_pos[j] = t; }
+                for (int f = 0; f < nb; f++) for (int i = 0; i < n_punct; i++) llr[(size_t)f * N + par_pos[i]] = 0.0f;          /* main.cpp:359-362 */
+            }
             const double t0 = now_s();
             if ((rc = qldpc_decode_siho(dec, llr, dec_bits, nb))) return die("decode_siho", rc);
             t_dec += now_s() - t0;
@@ -136,6 +155,6 @@ int main(int argc, char **argv)
         fflush(stdout);
     }
     qldpc_decoder_free(dec); qldpc_encoder_free(enc); qldpc_code_free(H);
-    free(pos); free(is_info); free(ref_bits); free(enc_bits); free(dec_bits); free(llr);
+    free(par_pos); free(pos); free(is_info); free(ref_bits); free(enc_bits); free(dec_bits); free(llr);
     return 0;
 }

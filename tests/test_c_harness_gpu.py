@@ -44,3 +44,16 @@ def test_alist_layered_minsum_runs():
     r = rows(out)
     assert len(r) == 1 and r[0]["fra"] == 200 and r[0]["fe"] <= 2
     assert "horizontal_layered" in out and "Info. bits (K) = 504" in out
+
+
+def test_puncturing_to_a_target_efficiency():
+    """main.cpp (parity bit puncture pattern finder): mother code rate 0.7, parity bits punctured (LLR 0) until the rate is
+    min_cr(QBER, f); at f = 1.8 and QBER 2 % the punctured code still decodes, the header reports rate and efficiency."""
+    out = run("-N", "16384", "-K", "11469", "-r", "SPA", "-i", "50", "-f", "64", "-b", "64", "-s", "0.02:0.02:0.01", "-e", "1.8")
+    r = rows(out)
+    assert len(r) == 1 and r[0]["fra"] == 64 and r[0]["fe"] <= 3
+    line = [l for l in out.splitlines() if "puncturing" in l][0]
+    import re
+    m = re.search(r"puncturing (\d+) of (\d+) parity bits -> rate ([0-9.]+), efficiency f = ([0-9.]+)", line)
+    n_p, n_par, rate, f = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert 0 < n_p < n_par and 0.70 < rate < 0.81 and 1.75 < f < 1.85
