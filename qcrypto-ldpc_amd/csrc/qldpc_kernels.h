@@ -39,10 +39,12 @@ struct qk_rule {
 
 /* ------------------------------------------------------------------ small helpers ------------ */
 
+typedef float qk_f32x2 __attribute__((ext_vector_type(2)));
+typedef float qk_f32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct qk_vec;
 template <> struct qk_vec<1> { typedef float t; };
-template <> struct qk_vec<2> { typedef float2 t; };
-template <> struct qk_vec<4> { typedef float4 t; };
+template <> struct qk_vec<2> { typedef qk_f32x2 t; };
+template <> struct qk_vec<4> { typedef qk_f32x4 t; };
 
 template <int V> __device__ __forceinline__ void qk_load(float (&d)[V], const float *p)
 {
@@ -58,6 +60,27 @@ template <int V> __device__ __forceinline__ void qk_store(float *p, const float 
 #pragma unroll
     for (int j = 0; j < V; j++) s[j] = d[j];
     *reinterpret_cast<typename qk_vec<V>::t *>(p) = t;
+}
+/*
+ * Streaming forms for the flooding message arrays: every row is read once and written once per pass and is
+ * not needed again for a whole iteration (7.7 GB later), so both directions carry the non-temporal hint.
+ * Measured on MI355X (4 096 frames): stores alone +4.5 %, loads alone -2 %, both +10.6 % (check-node kernel
+ * 5.33 -> 5.71 TB/s, variable-node passes 5.5 -> 6.25 TB/s).
+ */
+template <int V> __device__ __forceinline__ void qk_ldm(float (&d)[V], const float *p)
+{
+    typename qk_vec<V>::t t = __builtin_nontemporal_load(reinterpret_cast<const typename qk_vec<V>::t *>(p));
+    const float *s = reinterpret_cast<const float *>(&t);
+#pragma unroll
+    for (int j = 0; j < V; j++) d[j] = s[j];
+}
+template <int V> __device__ __forceinline__ void qk_stm(float *p, const float (&d)[V])
+{
+    typename qk_vec<V>::t t;
+    float *s = reinterpret_cast<float *>(&t);
+#pragma unroll
+    for (int j = 0; j < V; j++) s[j] = d[j];
+    __builtin_nontemporal_store(t, reinterpret_cast<typename qk_vec<V>::t *>(p));
 }
 /* store only the frames whose bit in keep[j] is set for this lane (frozen = converged frames) */
 template <int V> __device__ __forceinline__ void qk_store_masked(float *p, const float (&d)[V], const bool (&frozen)[V], bool any_frozen)
@@ -99,6 +122,34 @@ template <int V> __device__ __forceinline__ void qk_store_masked(__half *p, cons
     if (!any_frozen) { qk_store<V>(p, d); return; }
 #pragma unroll
     for (int j = 0; j < V; j++) if (!frozen[j]) p[j] = __float2half_rn(d[j]);
+}
+typedef unsigned qk_u32x2 __attribute__((ext_vector_type(2)));
+template <int V> __device__ __forceinline__ void qk_ldm(float (&d)[V], const __half *p)
+{
+    if constexpr (V == 1) { const unsigned short r = __builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p)); d[0] = __half2float(__ushort_as_half(r)); }
+    else if constexpr (V == 2) {
+        const unsigned r = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p));
+        const __half2 t = *reinterpret_cast<const __half2 *>(&r);
+        d[0] = __low2float(t); d[1] = __high2float(t);
+    } else {
+        const qk_u32x2 r = __builtin_nontemporal_load(reinterpret_cast<const qk_u32x2 *>(p));
+        const unsigned r0 = r.x, r1 = r.y;
+        const __half2 a = *reinterpret_cast<const __half2 *>(&r0), b = *reinterpret_cast<const __half2 *>(&r1);
+        d[0] = __low2float(a); d[1] = __high2float(a); d[2] = __low2float(b); d[3] = __high2float(b);
+    }
+}
+template <int V> __device__ __forceinline__ void qk_stm(__half *p, const float (&d)[V])
+{
+    if constexpr (V == 1) __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(d[0])), reinterpret_cast<unsigned short *>(p));
+    else if constexpr (V == 2) {
+        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1]));
+        __builtin_nontemporal_store(*reinterpret_cast<const unsigned *>(&a), reinterpret_cast<unsigned *>(p));
+    } else {
+        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1])), b = __halves2half2(__float2half_rn(d[2]), __float2half_rn(d[3]));
+        qk_u32x2 t;
+        t.x = *reinterpret_cast<const unsigned *>(&a); t.y = *reinterpret_cast<const unsigned *>(&b);
+        __builtin_nontemporal_store(t, reinterpret_cast<qk_u32x2 *>(p));
+    }
 }
 __device__ __forceinline__ void qk_put(float *p, float v) { *p = v; }
 __device__ __forceinline__ void qk_put(__half *p, float v) { *p = __float2half_rn(v); }
@@ -278,7 +329,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
         float x[DCMAX][V];
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
-            if (k < deg) qk_load<V>(x[k], vin + (size_t)slot[k] * FG);
+            if (k < deg) qk_ldm<V>(x[k], vin + (size_t)slot[k] * FG);
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
@@ -294,7 +345,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                     float o[V];
 #pragma unroll
                     for (int j = 0; j < V; j++) o[j] = acc[j].out(x[k][j], rule);
-                    qk_store<V>(cout + (size_t)slot[k] * FG, o);
+                    qk_stm<V>(cout + (size_t)slot[k] * FG, o);
                 }
         } else {
 #pragma unroll
@@ -367,7 +418,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
     for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
     float y[UN][V], tmp[UN][V];
 #pragma unroll
-    for (int u = 0; u < UN; u++) qk_load<V>(y[u], yin + (size_t)vv[u] * FG);
+    for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
 
     if constexpr (MODE == QK_VN_FIRST) {
 #pragma unroll
@@ -375,7 +426,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             float o[V];
 #pragma unroll
             for (int j = 0; j < V; j++) { tmp[u][j] = y[u][j] + 0.0f; o[j] = tmp[u][j] - 0.0f; }
-            for (int k = 0; k < dd[u]; k++) qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
+            for (int k = 0; k < dd[u]; k++) qk_stm<V>(vout + (size_t)(bb[u] + k) * FG, o);
         }
     } else if constexpr (DVMAX > 0) {
         float m[UN][DVMAX][V];
@@ -383,7 +434,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
         for (int u = 0; u < UN; u++) {
 #pragma unroll
             for (int k = 0; k < DVMAX; k++)
-                if (k < dd[u]) qk_load<V>(m[u][k], cin + (size_t)(bb[u] + k) * FG);
+                if (k < dd[u]) qk_ldm<V>(m[u][k], cin + (size_t)(bb[u] + k) * FG);
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
@@ -405,7 +456,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
                         float o[V];
 #pragma unroll
                         for (int j = 0; j < V; j++) o[j] = tmp[u][j] - m[u][k][j];
-                        qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
+                        qk_stm<V>(vout + (size_t)(bb[u] + k) * FG, o);
                     }
             }
         }
@@ -429,7 +480,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
                     qk_load<V>(m, cin + (size_t)(bb[u] + k) * FG);
 #pragma unroll
                     for (int j = 0; j < V; j++) o[j] = tmp[u][j] - m[j];
-                    qk_store<V>(vout + (size_t)(bb[u] + k) * FG, o);
+                    qk_stm<V>(vout + (size_t)(bb[u] + k) * FG, o);
                 }
             }
         }
