@@ -545,7 +545,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
                 qk_load<V>(x[k], pg + (size_t)vn[k] * FG);
-                qk_load<V>(m[k], mg + (size_t)(b + k) * FG);
+                qk_ldm<V>(m[k], mg + (size_t)(b + k) * FG);        /* the check's own messages: read once, written once per sweep */
             }
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
@@ -561,8 +561,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
                 float o[V], p[V];
 #pragma unroll
                 for (int j = 0; j < V; j++) { o[j] = acc[j].out(qk_prep<FAM>(x[k][j]), rule); p[j] = x[k][j] + o[j]; }
-                qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
-                qk_store_masked<V>(pg + (size_t)vn[k] * FG, p, frozen, any_frozen);
+                if (!any_frozen) qk_stm<V>(mg + (size_t)(b + k) * FG, o);
+                else qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);
+                qk_store_masked<V>(pg + (size_t)vn[k] * FG, p, frozen, any_frozen);      /* posteriors are re-read by later layers: cached */
             }
     } else {
         for (int k = 0; k < deg; k++) {
