@@ -202,8 +202,9 @@ template <> struct qk_acc<QK_FAM_MS> {
  * rcp units are used: tanh(a/2) = (1 - e^-a) / (1 + e^-a), 2 atanh(r) = ln((1 + r) / (1 - r)).  With the libm
  * forms the check-node kernel is compute-bound at 3x the min-sum time; with these it is HBM-bound again.
  */
-__device__ __forceinline__ float qk_tanh_half(float a) { const float e = __expf(-a); return __fdividef(1.0f - e, 1.0f + e); }
-__device__ __forceinline__ float qk_2atanh(float r) { return __logf(__fdividef(1.0f + r, 1.0f - r)); }
+__device__ __forceinline__ float qk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      /* v_rcp_f32, 1 ulp; __fdividef expands to the 10-instruction IEEE sequence */
+__device__ __forceinline__ float qk_tanh_half(float a) { const float e = __expf(-a); return (1.0f - e) * qk_rcp(1.0f + e); }
+__device__ __forceinline__ float qk_2atanh(float r) { return __logf((1.0f + r) * qk_rcp(1.0f - r)); }
 
 /* messages enter the SPA fold as sign-carrying tanh(|x|/2) so the value is computed once per edge */
 template <int FAM> __device__ __forceinline__ float qk_prep(float x) { return x; }
@@ -216,7 +217,7 @@ template <> struct qk_acc<QK_FAM_SPA> {
     __device__ __forceinline__ void finish(const qk_rule &) {}
     __device__ __forceinline__ float out(float xp, const qk_rule &) const
     {
-        float t = __fdividef(product, fabsf(xp));
+        float t = product * qk_rcp(fabsf(xp));
         t = (t < 1.0f) ? t : 1.0f - 1.1920928955078125e-07f;
         return qk_withsign(qk_2atanh(t), sign ^ qk_bits(xp));
     }

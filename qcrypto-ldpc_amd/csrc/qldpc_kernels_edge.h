@@ -112,7 +112,7 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
                 par ^= __shfl_xor(par, o);
             }
             if (act && !syndrome_only) {
-                float r = __fdividef(prod, t);
+                float r = prod * qk_rcp(t);
                 r = (r < 1.0f) ? r : 1.0f - 1.1920928955078125e-07f;
                 s_val[off + s] = qk_withsign(qk_2atanh(r), sg ^ qk_bits(x));
             }
