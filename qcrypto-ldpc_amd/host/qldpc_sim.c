@@ -11,6 +11,7 @@
  * usage: qldpc_sim [-N n] [-K k | -a alist | -q qc] [-r MS|OMS|NMS|SPA|LSPA|AMS_MIN|AMS_MINSTAR_L2|AMS_MINSTAR] [-p param]
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
  *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
+ *                  [-d parity_ber (dirty disclosed parity bits, BS/data_dvb/data5)]
  *                  [-e f (puncture parity bits to reach the rate min_cr(ber, f); random pattern re-drawn per batch, main.cpp:321-333,359-362)]
  */
 #include <math.h>
@@ -49,12 +50,13 @@ static int die(const char *what, int rc)
 int main(int argc, char **argv)
 {
     int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, opt;
+    double parity_ber = 0.0;      /* > 0: the disclosed parity bits are themselves wrong with this probability (main.cpp (test effect of dirty parities)) */
     double target_eff = 0.0;      /* > 0: puncture parity bits up to min_cr(ber, f), as BS/src/main.cpp:235-333 does */
     const char *alist = NULL, *qc = NULL, *rule_name = "NMS";
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:ln")) != -1) {
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:ln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -69,6 +71,7 @@ int main(int argc, char **argv)
         case 'S': seed = strtoull(optarg, NULL, 0); break;
         case 'P': peg = atoi(optarg); break;
         case 'e': target_eff = atof(optarg); break;
+        case 'd': parity_ber = atof(optarg); break;
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -133,7 +136,7 @@ int main(int argc, char **argv)
                 for (int v = 0; v < N; v++) {
                     const int x = enc_bits[(size_t)f * N + v];
                     if (is_info[v]) { const int y = x ^ (rng_unit() < ber); llr[(size_t)f * N + v] = y ? -L : L; }      /* BSC + demodulate */
-                    else llr[(size_t)f * N + v] = x ? -QLDPC_CONFIRMED_BIT_LLR : QLDPC_CONFIRMED_BIT_LLR;                /* disclosed parity */
+                    else { const int y = x ^ (parity_ber > 0.0 && rng_unit() < parity_ber); llr[(size_t)f * N + v] = y ? -QLDPC_CONFIRMED_BIT_LLR : QLDPC_CONFIRMED_BIT_LLR; }   /* disclosed parity (possibly dirty) */
                 }
             if (n_punct > 0) {      /* new random pattern per batch: partial Fisher-Yates over the parity positions */
                 for (int i = 0; i < n_punct; i++) { const int j = i + (int)(rng_next() % (uint64_t)(n_par - i)); const int t = par_pos[i]; par_pos[i] = par_pos[j]; par_pos[j] = t; }
