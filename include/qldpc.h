@@ -185,6 +185,15 @@ int qldpc_load_llr_dev(qldpc_decoder *dec, const float *d_llr, int n_frames);
  */
 int qldpc_load_bits_dev(qldpc_decoder *dec, const uint32_t *d_bits, const float *d_llr_mag,
                         const uint8_t *d_vn_class, int n_frames);
+/*
+ * Syndrome form: instead of pinning disclosed parity VNs, every check c must come out with the
+ * parity s_c that Alice computed on her key (s = H x_A).  d_synd_bits[n_frames][ceil(M/32)], MSB-first.  Call after
+ * qldpc_load_* (which clears it) and before qldpc_run; the success flag / early exit then test H x = s.  Works with
+ * any H (no encoder needed); not an AFF3CT configuration, so it is checked against the oracle's own coset mode.
+ */
+int qldpc_load_syndrome_dev(qldpc_decoder *dec, const uint32_t *d_synd_bits, int n_frames);
+/* s = H x for packed words d_bits[n_frames][ceil(N/32)] -> d_synd_bits[n_frames][ceil(M/32)] (Alice's side). */
+int qldpc_syndrome_dev(qldpc_decoder *dec, const uint32_t *d_bits, uint32_t *d_synd_bits, int n_frames);
 /* run the BP iterations on what was loaded. */
 int qldpc_run(qldpc_decoder *dec);
 /* fetch: hard decision of every VN, packed MSB-first, d_out[n_frames][ceil(N/32)]. */

@@ -50,6 +50,9 @@ def lib():
         L.orc_decode.restype = C.c_int
         L.orc_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, C.c_int,
                                  fp, ip, ip, ip, C.c_int]
+        L.orc_decode_coset.restype = C.c_int
+        L.orc_decode_coset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
+                                       fp, ip, ip, ip, C.c_int]
         L.orc_syndrome.restype = C.c_int
         L.orc_syndrome.argtypes = [C.c_void_p, ip, ip]
         up = C.POINTER(C.c_uint32)
@@ -123,7 +126,7 @@ class Graph:
 
 
 def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", enable_syndrome=True,
-           syndrome_depth=1, n_threads=1, msg_fp16=False):
+           syndrome_depth=1, n_threads=1, msg_fp16=False, target=None):
     """decode_siho on llr[n_frames, N]; returns dict(post, hard, iters, synd_ok)."""
     llr = np.ascontiguousarray(llr, dtype=np.float32)
     if llr.ndim == 1:
@@ -134,8 +137,12 @@ def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", ena
     hard = np.empty((F, N), np.int32)
     iters = np.empty(F, np.int32)
     ok = np.empty(F, np.int32)
-    rc = lib().orc_decode(graph._h, SCHEDULES[schedule], RULES[rule] | (0x100 if msg_fp16 else 0), float(param), int(n_ite), int(enable_syndrome),
-                          int(syndrome_depth), _fp(llr), F, _fp(post), _ip(hard), _ip(iters), _ip(ok), int(n_threads))
+    tgt = None
+    if target is not None:
+        tgt = np.ascontiguousarray(target, dtype=np.int32).reshape(F, graph.M)
+    rc = lib().orc_decode_coset(graph._h, SCHEDULES[schedule], RULES[rule] | (0x100 if msg_fp16 else 0), float(param), int(n_ite),
+                                int(enable_syndrome), int(syndrome_depth), _fp(llr), _ip(tgt) if tgt is not None else None, F, _fp(post),
+                                _ip(hard), _ip(iters), _ip(ok), int(n_threads))
     if rc != 0:
         raise RuntimeError("orc_decode failed: %d" % rc)
     return dict(post=post, hard=hard, iters=iters, synd_ok=ok)

@@ -27,6 +27,10 @@ struct orc_graph {
     int max_dc, max_dv;
 };
 
+/* per-thread decode context: target syndrome of the frame being decoded (coset / syndrome form) or NULL */
+static const int *g_synd = 0;
+#pragma omp threadprivate(g_synd)
+
 /* ------------------------------------------------------------------ graph ---------------- */
 
 /*
@@ -209,9 +213,11 @@ static inline float f_min_star_l2(float a, float b)
  * (begin_chk_node_in / compute_chk_node_in xdeg / end_chk_node_in / compute_chk_node_out xdeg),
  * selected at VAR/main.cpp (alist-v1.0.1):203-218 and BS/src/main.cpp:193.
  */
+static int g_cn_sign0 = 0;         /* initial sign of the fold: -1 when the check's target parity is 1 */
+#pragma omp threadprivate(g_cn_sign0)
 static void cn_update(int rule, float param, int deg, const float *in, float *out, float *scratch)
 {
-    int sign = 0;
+    int sign = g_cn_sign0;
     switch (rule) {
     case ORC_RULE_MS:
     case ORC_RULE_OMS:
@@ -302,7 +308,7 @@ static void cn_update(int rule, float param, int deg, const float *in, float *ou
 static int syndrome_is_zero(const orc_graph *g, const float *post)
 {
     for (int c = 0; c < g->M; c++) {
-        int s = 0;
+        int s = (g_synd && g_synd[c]) ? -1 : 0;
         for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) s ^= sgnbit(post[g->cn_var[j]]);
         if (s) return 0;
     }
@@ -371,6 +377,7 @@ static int decode_flooding(const orc_graph *g, int rule, float param, int n_ite,
         for (int c = 0; c < M; c++) {
             const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
             for (int i = 0; i < deg; i++) in[i] = v2c[g->transpose[b + i]];
+            g_cn_sign0 = (g_synd && g_synd[c]) ? -1 : 0;
             cn_update(rule, param, deg, in, out, scratch);
             for (int i = 0; i < deg; i++) c2v[g->transpose[b + i]] = stq(out[i]);
         }
@@ -415,6 +422,7 @@ static int decode_hlayered(const orc_graph *g, int rule, float param, int n_ite,
         for (int c = 0; c < M; c++) {
             const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
             for (int i = 0; i < deg; i++) in[i] = post[g->cn_var[b + i]] - msg[b + i];
+            g_cn_sign0 = (g_synd && g_synd[c]) ? -1 : 0;
             cn_update(rule, param, deg, in, out, scratch);
             for (int i = 0; i < deg; i++) { msg[b + i] = out[i]; post[g->cn_var[b + i]] = in[i] + out[i]; }
         }
@@ -432,6 +440,15 @@ static int decode_hlayered(const orc_graph *g, int rule, float param, int n_ite,
 int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int n_ite,
                int enable_syndrome, int syndrome_depth, const float *Y_N, int n_frames,
                float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
+{
+    return orc_decode_coset(g, schedule, rule, rule_param, n_ite, enable_syndrome, syndrome_depth, Y_N, 0, n_frames, post_out, hard, iters, synd_ok, n_threads);
+}
+
+/* Coset ("syndrome form") decoding: each frame f must satisfy H x = target[f] instead of H x = 0; the fold of check c
+ * starts with sign (-1)^target[f][c].  Not an AFF3CT mode: the oracle for the product's qldpc_load_syndrome_dev. */
+int orc_decode_coset(const orc_graph *g, int schedule, int rule, float rule_param, int n_ite,
+                     int enable_syndrome, int syndrome_depth, const float *Y_N, const int *target, int n_frames,
+                     float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
 {
     if (!g || !Y_N || n_frames < 0 || n_ite < 0) return -1;
     const int fp16 = (rule & ORC_MSG_FP16) != 0;      /* flag bit: messages stored as binary16 (flooding only) */
@@ -458,6 +475,8 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
 #endif
         for (int f = 0; f < n_frames; f++) {
             const float *Y = Y_N + (size_t)f * N;
+            g_synd = target ? target + (size_t)f * g->M : 0;
+            g_cn_sign0 = 0;
             int it;
             if (schedule == ORC_SCHED_FLOODING)
                 it = decode_flooding(g, rule, rule_param, n_ite, enable_syndrome, syndrome_depth, Y, post, a, b, in, out, scratch);
@@ -467,7 +486,15 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
             if (post_out) memcpy(post_out + (size_t)f * N, post, sizeof(float) * (size_t)N);
             if (hard) memcpy(hard + (size_t)f * N, hd, sizeof(int) * (size_t)N);
             if (iters) iters[f] = it;
-            if (synd_ok) synd_ok[f] = (orc_syndrome(g, hd, NULL) == 0);
+            if (synd_ok) {
+                int okf = 1;
+                for (int c = 0; c < g->M && okf; c++) {
+                    int pz = g_synd ? (g_synd[c] & 1) : 0;
+                    for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) pz ^= hd[g->cn_var[j]] & 1;
+                    if (pz) okf = 0;
+                }
+                synd_ok[f] = okf;
+            }
         }
         free(post); free(a); free(b); free(in); free(hd);
     }

@@ -75,6 +75,11 @@ int orc_decode(const orc_graph *g, int schedule, int rule, float rule_param, int
                int enable_syndrome, int syndrome_depth, const float *Y_N, int n_frames,
                float *post, int *hard, int *iters, int *synd_ok, int n_threads);
 
+/* Coset ("syndrome form") decoding: target[n_frames][M] of 0/1; frame f must satisfy H x = target[f]. */
+int orc_decode_coset(const orc_graph *g, int schedule, int rule, float rule_param, int n_ite,
+                     int enable_syndrome, int syndrome_depth, const float *Y_N, const int *target, int n_frames,
+                     float *post, int *hard, int *iters, int *synd_ok, int n_threads);
+
 /*
  * Privacy amplification hash, restating privAmp_doPrivAmp's loop (EC/subcomponents/priv_amp.c:213-218)
  * and the bit-serial LFSR of rnd_getPrngValue2_32 (EC/subcomponents/rnd.c:118-127, PRNG_FEEDBACK

@@ -104,6 +104,8 @@ _sig("qldpc_decoder_device_bytes", C.c_size_t, [_vp])
 _sig("qldpc_decode_siho", C.c_int, [_vp, _fp, _ip, C.c_int])
 _sig("qldpc_load_llr_dev", C.c_int, [_vp, _vp, C.c_int])
 _sig("qldpc_load_bits_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_int])
+_sig("qldpc_load_syndrome_dev", C.c_int, [_vp, _vp, C.c_int])
+_sig("qldpc_syndrome_dev", C.c_int, [_vp, _vp, _vp, C.c_int])
 _sig("qldpc_run", C.c_int, [_vp])
 _sig("qldpc_fetch_packed_dev", C.c_int, [_vp, _vp])
 _sig("qldpc_fetch_info_dev", C.c_int, [_vp, _vp])
@@ -325,6 +327,21 @@ class Decoder:
         self.n_frames = bits.shape[0]
         _chk(_L.qldpc_load_bits_dev(self._h, _vp(bits.data_ptr()), _vp(llr_mag.data_ptr()),
                                     _vp(vn_class.data_ptr()) if vn_class is not None else None, bits.shape[0]), "load_bits")
+
+    def load_syndrome(self, synd_bits):
+        """syndrome form: packed target syndromes [n_frames, ceil(M/32)] for the frames just loaded"""
+        torch = _torch()
+        Wm = (self.code.M + 31) // 32
+        assert synd_bits.is_cuda and synd_bits.dtype == torch.int32 and synd_bits.is_contiguous() and tuple(synd_bits.shape) == (self.n_frames, Wm)
+        _chk(_L.qldpc_load_syndrome_dev(self._h, _vp(synd_bits.data_ptr()), self.n_frames), "load_syndrome")
+
+    def syndrome_of(self, bits):
+        """s = H x for packed words [F, ceil(N/32)] -> [F, ceil(M/32)] (device)"""
+        torch = _torch()
+        assert bits.is_cuda and bits.dtype == torch.int32 and bits.is_contiguous() and bits.shape[1] == (self.N + 31) // 32
+        out = torch.empty((bits.shape[0], (self.code.M + 31) // 32), dtype=torch.int32, device=bits.device)
+        _chk(_L.qldpc_syndrome_dev(self._h, _vp(bits.data_ptr()), _vp(out.data_ptr()), bits.shape[0]), "syndrome_of")
+        return out
 
     def run(self):
         _chk(_L.qldpc_run(self._h), "run")

@@ -67,6 +67,9 @@ struct qldpc_decoder {
     int loaded, ran;
     int last_iters;
     int poll_every;
+    u64 *d_synd;                     /* [G][M][V] target-syndrome ballots (syndrome form), NULL until used */
+    uint32_t *e_synd;                /* edge engine: packed target syndromes [F][Wm] */
+    int has_synd;
     float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
     int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
@@ -150,7 +153,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
-    (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out);
+    (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
     if (d->h_done) (void)hipHostFree(d->h_done);
     for (auto &g : d->e_graphs) if (g) (void)hipGraphExecDestroy(g);
@@ -401,10 +404,10 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     if (d->msg_half)
         hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
-                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
+                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
     else
         hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, float>), grid, dim3(QK_THREADS), 0, d->stream, (const float *)d->d_a, d->d_b, b.d_list, b.n,
-                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
+                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
 }
 template <int V, int FAM>
 static void launch_cn_fam(qldpc_decoder *d, const bucket &b)
@@ -434,7 +437,7 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze);
+                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
 }
 template <int V, int FAM>
 static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
@@ -514,7 +517,7 @@ static int synd_pass(qldpc_decoder *d, const u64 *mask, int skip_done)
     prof_scope ps(d, KS_SYND, (double)d->E * 8.0 * d->G * V);
     int bx = std::max(1, std::min((d->M + 255) / 256, 4096 / std::max(1, d->G)));
     hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(256), 0, d->stream, mask, d->d_cn_ptr, d->d_cn_var, d->M, d->N,
-                       d->d_unsat, d->d_done, skip_done);
+                       d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr);
     LAUNCHCHK();
     return QLDPC_OK;
 }
@@ -625,10 +628,10 @@ static void launch_qe_cn(qldpc_decoder *d, const uint32_t *bits, int slot, int s
     float *c2v_out = (slot & 1) ? d->e_c2v1 : d->d_b;        /* ping-pong by iteration parity */
     if (d->cfg.rule == QLDPC_RULE_SPA)
         hipLaunchKernelGGL((qe_cn<S, QK_FAM_SPA>), grid, dim3(QE_THREADS), 0, d->stream, d->d_a, c2v_out, d->d_cn_ptr, d->d_cn_tr, d->d_cn_var, bits,
-                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only);
+                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only, d->has_synd ? d->e_synd : nullptr, (d->M + 31) / 32);
     else
         hipLaunchKernelGGL((qe_cn<S, QK_FAM_MS>), grid, dim3(QE_THREADS), 0, d->stream, d->d_a, c2v_out, d->d_cn_ptr, d->d_cn_tr, d->d_cn_var, bits,
-                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only);
+                           d->M, d->E, d->eW, d->e_unsat, d->e_stride, slot, d->e_done_at, r, syndrome_only, d->has_synd ? d->e_synd : nullptr, (d->M + 31) / 32);
 }
 static int edge_cn(qldpc_decoder *d, const uint32_t *bits, int slot, int syndrome_only)
 {
@@ -784,6 +787,7 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
     d->n_frames = n_frames;
+    d->has_synd = 0;
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
         HIPCHK(hipMemcpyAsync(d->d_llr, d_llr, sizeof(float) * (size_t)n_frames * d->N, hipMemcpyDeviceToDevice, d->stream));
@@ -811,6 +815,7 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
     d->n_frames = n_frames;
+    d->has_synd = 0;
     const int W = (d->N + 31) / 32;
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
@@ -831,6 +836,43 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
         LAUNCHCHK();
     }
     d->loaded = 1; d->ran = 0;
+    return QLDPC_OK;
+}
+
+/* syndrome form: target syndromes for the frames just loaded (cleared again by the next qldpc_load_*) */
+extern "C" int qldpc_load_syndrome_dev(qldpc_decoder *d, const uint32_t *d_synd_bits, int n_frames)
+{
+    if (!d || !d_synd_bits) return QLDPC_EINVAL;
+    if (!d->loaded || n_frames != d->n_frames) { qldpc_set_error("qldpc_load_syndrome_dev: load %d frames first (have %d)", n_frames, d->loaded ? d->n_frames : 0); return QLDPC_ESTATE; }
+    HIPCHK(hipSetDevice(d->device));
+    const int Wm = (d->M + 31) / 32;
+    int rc;
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        if (!d->e_synd && (rc = dev_alloc(d, &d->e_synd, (size_t)d->cfg.max_frames * Wm))) return rc;
+        HIPCHK(hipMemcpyAsync(d->e_synd, d_synd_bits, sizeof(uint32_t) * (size_t)n_frames * Wm, hipMemcpyDeviceToDevice, d->stream));
+    } else {
+        if (!d->d_synd && (rc = dev_alloc(d, &d->d_synd, (size_t)d->G * d->M * d->V))) return rc;
+        dim3 grid((unsigned)std::max(1, std::min((Wm + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_load_syndrome<1>), grid, dim3(QK_THREADS), 0, d->stream, d_synd_bits, d->d_synd, d->M, Wm, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_load_syndrome<2>), grid, dim3(QK_THREADS), 0, d->stream, d_synd_bits, d->d_synd, d->M, Wm, n_frames); break;
+        default: hipLaunchKernelGGL((qk_load_syndrome<4>), grid, dim3(QK_THREADS), 0, d->stream, d_synd_bits, d->d_synd, d->M, Wm, n_frames); break;
+        }
+        LAUNCHCHK();
+    }
+    d->has_synd = 1; d->ran = 0;
+    return QLDPC_OK;
+}
+
+/* s = H x on the device for packed words (Alice's side of the syndrome form; also a codeword test) */
+extern "C" int qldpc_syndrome_dev(qldpc_decoder *d, const uint32_t *d_bits, uint32_t *d_synd_bits, int n_frames)
+{
+    if (!d || !d_bits || !d_synd_bits || n_frames <= 0) return QLDPC_EINVAL;
+    HIPCHK(hipSetDevice(d->device));
+    const int Wn = (d->N + 31) / 32, Wm = (d->M + 31) / 32;
+    hipLaunchKernelGGL(qk_syndrome_of_bits, dim3((unsigned)((Wm + 255) / 256), (unsigned)n_frames), dim3(256), 0, d->stream, d_bits, d->d_cn_ptr, d->d_cn_var, d_synd_bits,
+                       d->M, Wn, Wm);
+    LAUNCHCHK();
     return QLDPC_OK;
 }
 

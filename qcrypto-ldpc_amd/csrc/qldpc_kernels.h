@@ -303,7 +303,7 @@ template <int V, int DCMAX, int FAM, typename MT>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__ v2c, MT *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
-                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze)
+                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -322,7 +322,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
     const int deg = cn_ptr[c + 1] - b;
     qk_acc<FAM> acc[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) acc[j].begin();
+    for (int j = 0; j < V; j++) {
+        acc[j].begin();
+        /* syndrome form: the check must come out with parity s_c, i.e. its sign product starts at (-1)^s_c */
+        if (synd) acc[j].sign = (uint32_t)((synd[((size_t)g * M + c) * V + j] >> lane) & 1ull) << 31;
+    }
     if constexpr (DCMAX > 0) {
         int slot[DCMAX];
 #pragma unroll
@@ -517,7 +521,7 @@ template <int V, int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ post, float *__restrict__ msg,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
-                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze)
+                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -536,7 +540,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
     const int deg = cn_ptr[c + 1] - b;
     qk_acc<FAM> acc[V];
 #pragma unroll
-    for (int j = 0; j < V; j++) acc[j].begin();
+    for (int j = 0; j < V; j++) {
+        acc[j].begin();
+        /* syndrome form: the check must come out with parity s_c, i.e. its sign product starts at (-1)^s_c */
+        if (synd) acc[j].sign = (uint32_t)((synd[((size_t)g * M + c) * V + j] >> lane) & 1ull) << 31;
+    }
     if constexpr (DCMAX > 0) {
         int vn[DCMAX];
 #pragma unroll
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
 template <int V>
 __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_ptr,
                                                    const int *__restrict__ cn_var, int M, int N,
-                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done)
+                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done, const u64 *__restrict__ synd)
 {
     const int g = blockIdx.y;
     if (skip_done && qk_group_done<V>(done, g)) return;
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask,
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < M; c += gridDim.x * blockDim.x) {
         u64 s[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) s[j] = 0;
+        for (int j = 0; j < V; j++) s[j] = synd ? synd[((size_t)g * M + c) * V + j] : 0ull;      /* H x must equal the target syndrome */
         for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++) {
             const u64 *p = mg + (size_t)cn_var[k] * V;
 #pragma unroll
@@ -795,6 +803,49 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
             }
             qk_store<V>(dst + ((size_t)g * N + v) * FG + lane * V, o);
         }
+    }
+}
+
+/* packed MSB-first syndrome words synd_bits[n_frames][Wm] -> per-check ballots synd[G][M][V] (bit = lane) */
+template <int V>
+__global__ __launch_bounds__(QK_THREADS) void qk_load_syndrome(const uint32_t *__restrict__ bits, u64 *__restrict__ synd, int M, int Wm, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int w = blockIdx.x * QK_WAVES + wave; w < Wm; w += gridDim.x * QK_WAVES) {
+        uint32_t word[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) { const int f = g * FG + lane * V + j; word[j] = f < n_frames ? bits[(size_t)f * Wm + w] : 0u; }
+        for (int b = 0; b < 32; b++) {
+            const int c = w * 32 + b;
+            if (c >= M) break;
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const u64 m = __ballot((word[j] >> (31 - b)) & 1u);
+                if (lane == 0) synd[((size_t)g * M + c) * V + j] = m;
+            }
+        }
+    }
+}
+
+/* s = H x for packed words x[n_frames][Wn] -> s[n_frames][Wm] (Alice's side of the syndrome form) */
+__global__ __launch_bounds__(256) void qk_syndrome_of_bits(const uint32_t *__restrict__ x, const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
+                                                           uint32_t *__restrict__ s, int M, int Wn, int Wm)
+{
+    const int f = blockIdx.y;
+    const uint32_t *xf = x + (size_t)f * Wn;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < Wm; w += gridDim.x * blockDim.x) {
+        uint32_t word = 0;
+        for (int b = 0; b < 32; b++) {
+            const int c = w * 32 + b;
+            if (c >= M) break;
+            uint32_t p = 0;
+            for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++) { const int v = cn_var[k]; p ^= (xf[v >> 5] >> (31 - (v & 31))) & 1u; }
+            word |= p << (31 - b);
+        }
+        s[(size_t)f * Wm + w] = word;
     }
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
                                                     const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                                     const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
                                                     int M, int E, int W, int *__restrict__ unsat, int unsat_stride, int ite,
-                                                    const int *__restrict__ done_at, qk_rule rule, int syndrome_only)
+                                                    const int *__restrict__ done_at, qk_rule rule, int syndrome_only, const uint32_t *__restrict__ synd, int Wm)
 {
     __shared__ int s_idx[QE_MAX_EDGES];
     __shared__ float s_val[QE_MAX_EDGES];
@@ -82,9 +82,12 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
         const bool act = s < deg;
         const float x = act ? s_val[off + s] : 0.0f;
         uint32_t par = act ? ((uint32_t)s_idx[off + s] >> 31) : 0u;
+        /* syndrome form: lane 0 of the segment carries the target parity s_c into both folds */
+        const uint32_t sc = (synd && live && s == 0) ? ((synd[(size_t)f * Wm + (c >> 5)] >> (31 - (c & 31))) & 1u) : 0u;
+        par ^= sc;
         if constexpr (FAM == QK_FAM_MS) {
             float m1 = act ? fabsf(x) : 3.402823466e+38f, m2 = 3.402823466e+38f;
-            uint32_t sg = act ? (qk_bits(x) & 0x80000000u) : 0u;
+            uint32_t sg = (act ? (qk_bits(x) & 0x80000000u) : 0u) ^ (sc << 31);
 #pragma unroll
             for (int o = 1; o < S; o <<= 1) {
                 const float p1 = __shfl_xor(m1, o), p2 = __shfl_xor(m2, o);
@@ -99,12 +102,12 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
                 if (rule.rule == 0)      { cst1 = qk_max(0.0f, m2);              cst2 = qk_max(0.0f, m1); }
                 else if (rule.rule == 1) { cst1 = qk_max(0.0f, m2 - rule.param); cst2 = qk_max(0.0f, m1 - rule.param); }
                 else                     { cst1 = m2 * rule.param;               cst2 = m1 * rule.param; }
-                s_val[off + s] = qk_withsign((fabsf(x) == m1) ? cst1 : cst2, sg ^ qk_bits(x));
+                s_val[off + s] = qk_withsign((fabsf(x) == m1) ? cst1 : cst2, sg ^ qk_bits(x));      /* sg already folds s_c in */
             }
         } else {   /* SPA: the product is reduced as a tree, so it is tolerance-class (not order-exact) */
             const float t = act ? qk_tanh_half(fabsf(x)) : 1.0f;
             float prod = t;
-            uint32_t sg = act ? (qk_bits(x) & 0x80000000u) : 0u;
+            uint32_t sg = (act ? (qk_bits(x) & 0x80000000u) : 0u) ^ (sc << 31);
 #pragma unroll
             for (int o = 1; o < S; o <<= 1) {
                 prod *= __shfl_xor(prod, o);
