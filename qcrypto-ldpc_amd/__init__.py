@@ -332,8 +332,8 @@ class Decoder:
         """syndrome form: packed target syndromes [n_frames, ceil(M/32)] for the frames just loaded"""
         torch = _torch()
         Wm = (self.code.M + 31) // 32
-        assert synd_bits.is_cuda and synd_bits.dtype == torch.int32 and synd_bits.is_contiguous() and tuple(synd_bits.shape) == (self.n_frames, Wm)
-        _chk(_L.qldpc_load_syndrome_dev(self._h, _vp(synd_bits.data_ptr()), self.n_frames), "load_syndrome")
+        assert synd_bits.is_cuda and synd_bits.dtype == torch.int32 and synd_bits.is_contiguous() and synd_bits.shape[1] == Wm
+        _chk(_L.qldpc_load_syndrome_dev(self._h, _vp(synd_bits.data_ptr()), synd_bits.shape[0]), "load_syndrome")
 
     def syndrome_of(self, bits):
         """s = H x for packed words [F, ceil(N/32)] -> [F, ceil(M/32)] (device)"""
