@@ -8,8 +8,10 @@
 #include "ldpc_reconcile.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include "subcomponents/cascade_biconf.h"
 #include "subcomponents/comms.h"
 #include "subcomponents/debug.h"
 #include "subcomponents/helpers.h"
@@ -105,6 +107,78 @@ static int ldpc_setup(ProcessBlock *pb, PROCESSOR_ROLE role)
     return 0;
 }
 
+/* A block LDPC could not reconcile (no codeword within the iteration budget, or CRC mismatch) is handed to
+ * the sibling algorithm instead of being dropped: same role, the cascade managers, and the set-up the
+ * cascade arms of qber_estim.c:306-334 / :397-421 do.  The parity and CRC bits already disclosed stay in
+ * leakageBits, so privacy amplification accounts for both attempts.  ECD2_LDPC_FALLBACK=0 restores "drop". */
+static int ldpc_fallbackEnabled(void)
+{
+    const char *e = getenv("ECD2_LDPC_FALLBACK");
+    return !(e && e[0] == '0');
+}
+
+/* cascade begins with helper_cleanupRevealedBits once more (helper_prepPermutationWrapper, helpers.c:79-82), which
+ * (a) would overwrite the already compacted key at the marked positions and (b) zeroes leakageBits.  (a): rewrite the
+ * marker so that a second clean-up is the identity on mainBufPtr[0..workbits).  (b): the bits LDPC spent are carried
+ * past that reset -- by the caller on the initiator side, by a wrapped subtype-4 handler on the follower side. */
+static void ldpc_normaliseMarkers(ProcessBlock *pb)
+{
+    int i;
+    for (i = 0; i < pb->initialBits; i++) {
+        const unsigned int bm = uint32AllZeroExceptAtN(i);
+        if (i < pb->workbits) pb->testedBitsMarker[wordIndex(i)] &= ~bm;
+        else pb->testedBitsMarker[wordIndex(i)] |= bm;
+    }
+}
+
+#define LDPC_FALLBACK_SLOTS 64
+static struct { unsigned int epoch; int spentBits; int used; } g_fallback[LDPC_FALLBACK_SLOTS];
+
+static int ldpc_fallbackStartBinSearch(ProcessBlock *pb, char *receivebuf)
+{
+    int i, spent = 0, errorCode;
+    for (i = 0; i < LDPC_FALLBACK_SLOTS; i++)
+        if (g_fallback[i].used && g_fallback[i].epoch == pb->startEpoch) { spent = g_fallback[i].spentBits; g_fallback[i].used = 0; break; }
+    errorCode = cascade_startBinSearch(pb, receivebuf);
+    pb->leakageBits += spent;
+    return errorCode;
+}
+
+/* the cascade follower's table (definitions/algorithms/algorithms.c:80-93) with subtype 4 wrapped */
+static const PacketHandlerArray ALG_PKTHNDLRS_LDPC_FALLBACK_FOLLOWER = {
+    ldpc_fallbackStartBinSearch,            /* subtype 4 */
+    cascade_followerBob_processBinSearch,   /* subtype 5 */
+    cascade_generateBiconfReply,            /* subtype 6 */
+    cascade_receiveBiconfReply,             /* subtype 7 */
+    privAmp_receivePrivAmpMsg               /* subtype 8 */
+};
+static const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER = { &ALG_PKTHNDLRS_LDPC_FALLBACK_FOLLOWER, SUBTYPE_CASCADE_PARITY_LIST, SUBTYPE_START_PRIV_AMP, False };
+
+static int ldpc_fallBackToCascade(ProcessBlock *pb, PROCESSOR_ROLE role)
+{
+    const int spent = pb->leakageBits;
+    int errorCode, i;
+    if ((errorCode = pb->algorithmDataMngr->freeData(pb))) return errorCode;
+    pb->processorRole = role;
+    pb->algorithmPktMngr = (ALGORITHM_PKT_MNGR *)(role == PROC_ROLE_EC_INITIATOR ? &ALG_PKT_MNGR_CASCADE_INITIATOR : &ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER);
+    pb->algorithmDataMngr = (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_CASCADE;
+    if ((errorCode = pb->algorithmDataMngr->initData(pb))) return errorCode;
+    ldpc_normaliseMarkers(pb);
+    printf("ldpc: epoch %08x: falling back to cascade as EC %s, %d bits already leaked\n", pb->startEpoch,
+           role == PROC_ROLE_EC_INITIATOR ? "initiator" : "follower", spent);
+    fflush(stdout);
+    if (role == PROC_ROLE_EC_INITIATOR) {
+        errorCode = cascade_initiateAfterQber(pb);
+        pb->leakageBits += spent;
+        return errorCode;
+    }
+    for (i = 0; i < LDPC_FALLBACK_SLOTS && g_fallback[i].used; i++) ;
+    if (i == LDPC_FALLBACK_SLOTS) return LDPC_ERR_ENGINE;
+    g_fallback[i].epoch = pb->startEpoch; g_fallback[i].spentBits = spent; g_fallback[i].used = 1;
+    cascade_calck0k1(pb);
+    return 0;           /* await the initiator's parity list (subtype 4) */
+}
+
 /* ---- hooks for qber_estim.c ------------------------------------------------------------------- */
 
 int ldpc_prepareAsQberFollower(ProcessBlock *pb, ALGORITHM_DECISION chosenAlgorithm, char *ackToSend, unsigned int ackLength)
@@ -155,6 +229,14 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
     h9->codeK = msg.code_k;
     h9->codeM = msg.code_m;
     h9->crc32 = msg.crc32;
+    {   /* fault injection for tests of the fallback path: ECD2_LDPC_FAULT=n flips n disclosed parity bits */
+        const char *fault = getenv("ECD2_LDPC_FAULT");
+        int n = fault ? atoi(fault) : 0, i;
+        for (i = 0; i < n && i < (int)msg.code_m; i++) {
+            const int pos = i * 97 % (int)msg.code_m;
+            ((uint32_t *)&h9[1])[pos / 32] ^= 1u << (31 - pos % 32);
+        }
+    }
     ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m;
 
     pb->processingState = PSTATE_PERFORMED_PARITY;
@@ -194,7 +276,10 @@ int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
     if ((errorCode = comms_insertSendPacket((char *)h10, h10->base.totalLengthInBytes))) return errorCode;
 
     if (rc == QLDPC_EDECODE) {
-        /* no codeword found or CRC mismatch: the block cannot be used */
+        /* no codeword found or CRC mismatch: mainBufPtr is untouched, the disclosed bits are spent */
+        printf("ldpc: epoch %08x: no verified codeword after %d iterations\n", pb->startEpoch, iterations);
+        pb->leakageBits += leaked;
+        if (ldpc_fallbackEnabled()) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_FOLLOWER);
         pBlkMgmt_removeProcessBlk(pb->startEpoch);
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
@@ -215,6 +300,7 @@ int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
     EcPktHdr_LdpcVerdict *in_head = (EcPktHdr_LdpcVerdict *)receivebuf;
     if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) return LDPC_ERR_PKT_SIZE;
     if (!in_head->decoded) {
+        if (ldpc_fallbackEnabled()) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_INITIATOR);
         pBlkMgmt_removeProcessBlk(pb->startEpoch);
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }

@@ -43,7 +43,7 @@ typedef struct ERRC_LDPC_9 {
 /** @brief subtype 10: verdict */
 typedef struct ERRC_LDPC_10 {
     EcPktHdr_Base base;
-    unsigned int decoded;         /**< 1: follower holds the initiator's key, PA message follows; 0: drop the block */
+    unsigned int decoded;         /**< 1: follower holds the initiator's key, PA message follows; 0: both sides fall back to cascade (or drop the block if ECD2_LDPC_FALLBACK=0) */
     unsigned int correctedBits;
     unsigned int iterations;
 } EcPktHdr_LdpcVerdict;

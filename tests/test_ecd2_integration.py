@@ -126,3 +126,25 @@ def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
     for o in (o1, o2):
         assert o["a_final"] is not None and (o["a_final"]["words"] == o["b_final"]["words"]).all()
     assert o1["a_final"]["nbits"] > 0 and o2["a_final"]["nbits"] > 0
+
+
+@pytest.mark.gpu
+def test_decode_failure_falls_back_to_cascade(tmp_path):
+    """SURVEY.md section 8(f)1 "fallback to cascade on decode failure": Alice's parity packet is corrupted on purpose
+    (ECD2_LDPC_FAULT flips disclosed parity bits), Bob finds no verified codeword, says so in the verdict, and both
+    daemons finish the block with the reference's own cascade exchange. The final keys are identical and shorter than
+    in the clean LDPC run, because the wasted parity + CRC bits stay in leakageBits."""
+    binary = need("ecd2_ldpc")
+    a, b = epochs(7, 4, 6000, 0.02)
+    clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"})
+    out = run_loopback(binary, tmp_path / "fault", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_LDPC_FAULT": "600"})
+    assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
+    assert "no verified codeword" in out["b_log"]
+    assert "falling back to cascade as EC follower" in out["b_log"] and "falling back to cascade as EC initiator" in out["a_log"]
+    assert "Prep to send pkt subtype 4\n" in out["a_log"]            # the cascade parity list really went out
+    assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0
+    assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
+    assert 0 < out["a_final"]["nbits"] < clean["a_final"]["nbits"]
+    # dropping instead of falling back is still available
+    drop = run_loopback(binary, tmp_path / "drop", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_LDPC_FAULT": "600", "ECD2_LDPC_FALLBACK": "0"}, timeout=8)
+    assert drop["a_final"] is None and drop["b_final"] is None
