@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-message-storage variant leg")
+    ap.add_argument("--no-int8", action="store_true", help="skip the 8-bit fixed-point variant leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -211,7 +212,7 @@ def main():
     fer = 1.0 - good / n_all
     if args.schedule != "flooding":          # experiment mode: one kernel family, no CPU / fp16 legs
         kstats["cn_update"] = kstats["vn_update"] = kstats["layer_update"]
-        args.no_fp16 = args.no_cpu = True
+        args.no_fp16 = args.no_int8 = args.no_cpu = True
     cn = kstats["cn_update"]
     vn = kstats["vn_update"]
     cn_avg_s = cn["total_ms"] / cn["launches"] * 1e-3
@@ -235,13 +236,14 @@ def main():
         del dec
         torch.cuda.empty_cache()
 
-    # ---- variant (NOT the headline): messages stored as binary16, fp32 arithmetic ----------------------------
-    # FER-tolerance class against the AFF3CT float build; bit-exact against the oracle with the same rounding.
-    fp16 = None
-    if not args.no_fp16:
-        fp16 = {}
+    # ---- variants (NOT the headline): narrower message storage -------------------------------------------------
+    # f16: messages rounded to binary16 in HBM, fp32 arithmetic.  i8: 8-bit fixed-point min-sum (quantiser 4 steps per LLR
+    # unit, messages saturating at +-127).  Both are FER-tolerance class against the AFF3CT float build and bit-exact
+    # against the oracle run with the same arithmetic (tests/test_parity_gpu.py, tests/test_i8_gpu.py).
+    def variant(msg_dtype):
+        res = {}
         for name, synd in (("fixed", False), ("early_exit", True)):
-            dec = make_decoder(synd, "f16")
+            dec = make_decoder(synd, msg_dtype)
             dec.profile(True)
             step(dec)
             dec.profile_clear()
@@ -249,12 +251,17 @@ def main():
             ks = {s["name"]: s for s in dec.profile_read()}
             dec.profile(False)
             gh, ith, nh = verdicts(dec)
-            cnh = ks["cn_update"]
-            fp16[name] = dict(value=gh * K * max(1, args.steps) / dth / 1e6, unit="Mbit/s", fer=1.0 - gh / nh, avg_iterations=ith / nh,
-                              ms_per_step=dth / max(1, args.steps) * 1e3,
-                              cn_update_GBs=(cnh["alg_bytes"] / cnh["launches"]) / (cnh["total_ms"] / cnh["launches"] * 1e-3) / 1e9)
+            cnh, vnh = ks["cn_update"], ks["vn_update"]
+            res[name] = dict(value=gh * K * max(1, args.steps) / dth / 1e6, unit="Mbit/s", fer=1.0 - gh / nh, avg_iterations=ith / nh,
+                             ms_per_step=dth / max(1, args.steps) * 1e3,
+                             cn_update_GBs=(cnh["alg_bytes"] / cnh["launches"]) / (cnh["total_ms"] / cnh["launches"] * 1e-3) / 1e9,
+                             vn_update_GBs=(vnh["alg_bytes"] / vnh["launches"]) / (vnh["total_ms"] / vnh["launches"] * 1e-3) / 1e9)
             del dec
             torch.cuda.empty_cache()
+        return res
+
+    fp16 = variant("f16") if not args.no_fp16 else None
+    int8 = variant("i8") if (not args.no_int8 and args.rule in ("MS", "OMS", "NMS")) else None
 
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------
     cpu = None
@@ -327,6 +334,7 @@ def main():
             "cpu_baseline": cpu,
             "early_exit": early,
             "fp16_messages": fp16,
+            "int8_messages": int8,
             "reference_context": {"aff3ct_spa_1thread_debug_Mbit_s": 0.241, "cascade_daemon_Mbit_s": 0.3},
         }
         print(json.dumps(line), flush=True)

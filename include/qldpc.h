@@ -156,8 +156,14 @@ typedef struct qldpc_decoder_cfg {
                             0 = only its hard decisions / iteration count / success flag are frozen (default)      */
     int msg_dtype;       /* 0 = fp32 messages (the AFF3CT float build, bit-exact class); 1 = messages rounded to
                             binary16 in HBM, fp32 arithmetic (half the bytes per iteration; FER-tolerance class against
-                            AFF3CT, bit-exact against the oracle run with the same rounding; FRAMES engine, flooding) */
-    int reserved[4];     /* must be zero                                                         */
+                            AFF3CT, bit-exact against the oracle run with the same rounding; FRAMES engine, flooding);
+                            2 = 8-bit fixed point: channel LLRs quantised to clamp(rint(LLR * quant_scale), +-127), messages
+                            saturating at +-127, integer min-sum (MS / OMS / NMS, flooding, FRAMES engine, 4 frames per lane):
+                            a quarter of the bytes per iteration, FER-tolerance class against AFF3CT, bit-exact against the
+                            oracle's integer decoder; qldpc_fetch_post_dev then returns the integer posteriors           */
+    float quant_scale;   /* msg_dtype 2: quantiser steps per LLR unit (0 = 4.0); OMS offset = rint(rule_param * quant_scale)
+                            steps, NMS factor = rint(rule_param * 128) / 128                                          */
+    int reserved[3];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
 void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);

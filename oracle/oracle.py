@@ -53,6 +53,9 @@ def lib():
         L.orc_decode_coset.restype = C.c_int
         L.orc_decode_coset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
                                        fp, ip, ip, ip, C.c_int]
+        L.orc_decode_i8.restype = C.c_int
+        L.orc_decode_i8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
+                                    fp, ip, ip, ip, C.c_int]
         L.orc_syndrome.restype = C.c_int
         L.orc_syndrome.argtypes = [C.c_void_p, ip, ip]
         up = C.POINTER(C.c_uint32)
@@ -126,8 +129,9 @@ class Graph:
 
 
 def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", enable_syndrome=True,
-           syndrome_depth=1, n_threads=1, msg_fp16=False, target=None):
-    """decode_siho on llr[n_frames, N]; returns dict(post, hard, iters, synd_ok)."""
+           syndrome_depth=1, n_threads=1, msg_fp16=False, target=None, msg_i8=False, quant_scale=4.0):
+    """decode_siho on llr[n_frames, N]; returns dict(post, hard, iters, synd_ok).
+    msg_i8: the 8-bit fixed-point flooding min-sum (orc_decode_i8); post then holds the integer posteriors."""
     llr = np.ascontiguousarray(llr, dtype=np.float32)
     if llr.ndim == 1:
         llr = llr[None, :]
@@ -140,6 +144,13 @@ def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", ena
     tgt = None
     if target is not None:
         tgt = np.ascontiguousarray(target, dtype=np.int32).reshape(F, graph.M)
+    if msg_i8:
+        assert schedule == "flooding" and not msg_fp16
+        rc = lib().orc_decode_i8(graph._h, RULES[rule], float(param), float(quant_scale), int(n_ite), int(enable_syndrome), int(syndrome_depth),
+                                 _fp(llr), _ip(tgt) if tgt is not None else None, F, _fp(post), _ip(hard), _ip(iters), _ip(ok), int(n_threads))
+        if rc != 0:
+            raise RuntimeError("orc_decode_i8 failed: %d" % rc)
+        return dict(post=post, hard=hard, iters=iters, synd_ok=ok)
     rc = lib().orc_decode_coset(graph._h, SCHEDULES[schedule], RULES[rule] | (0x100 if msg_fp16 else 0), float(param), int(n_ite),
                                 int(enable_syndrome), int(syndrome_depth), _fp(llr), _ip(tgt) if tgt is not None else None, F, _fp(post),
                                 _ip(hard), _ip(iters), _ip(ok), int(n_threads))

@@ -501,6 +501,129 @@ int orc_decode_coset(const orc_graph *g, int schedule, int rule, float rule_para
     return 0;
 }
 
+/* ------------------------------------------------------------- 8-bit fixed point --------- */
+
+/*
+ * Saturating fixed-point flooding min-sum, the integer decoder the product's msg_dtype = 2 kernels must equal bit for
+ * bit.  Not an AFF3CT float mode (FER-tolerance class against it); the recipe -- quantise, subtract, saturate,
+ * min1/min2/parity, offset or scale, saturate -- is the one of the reference's fixed-point MATLAB decoder
+ * (ldpc_examples/.../BPSK_nrldpc_sim_RM_FP.m:37-98) applied to the flooding schedule above:
+ *   Yq = clamp(rint(Y * scale), +-127); tmp = Yq + sum chk_to_var; var_to_chk = clamp(tmp - chk_to_var, +-127);
+ *   |chk_to_var| = rule(min over the other edges), MS: m, OMS: max(0, m - rint(offset * scale)), NMS: (m * rint(factor * 128)) >> 7;
+ *   decision = tmp < 0; early exit and iteration count exactly as decode_flooding.
+ */
+static int i8_quant(float y, float scale)
+{
+    const float t = y * scale;
+    if (!(t < 127.0f)) return 127;
+    if (t < -127.0f) return -127;
+    return (int)lrintf(t);
+}
+static int i8_norm(int m, int rule, int p)
+{
+    if (rule == ORC_RULE_MS) return m;
+    if (rule == ORC_RULE_OMS) return m > p ? m - p : 0;
+    return (m * p) >> 7;
+}
+static int i8_syndrome_is_zero(const orc_graph *g, const int *post, const int *target)
+{
+    for (int c = 0; c < g->M; c++) {
+        int s = target ? (target[c] & 1) : 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) s ^= post[g->cn_var[j]] < 0;
+        if (s) return 0;
+    }
+    return 1;
+}
+static int decode_flooding_i8(const orc_graph *g, int rule, int p, int n_ite, int enable_syndrome, int syndrome_depth,
+                              const int *Yq, const int *target, int *post, int *c2v, int *v2c)
+{
+    const int N = g->N, M = g->M, E = g->E;
+    memset(c2v, 0, sizeof(int) * (size_t)E);
+    int cur_depth = 0, ite = 0;
+    for (; ite < n_ite; ite++) {
+        for (int v = 0; v < N; v++) {
+            int sum = 0;
+            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+            const int tmp = Yq[v] + sum;
+            for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) {
+                int x = tmp - c2v[e];
+                v2c[e] = x > 127 ? 127 : (x < -127 ? -127 : x);
+            }
+        }
+        for (int c = 0; c < M; c++) {
+            const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
+            int sign = target ? (target[c] & 1) : 0, min1 = 127, min2 = 127;
+            for (int i = 0; i < deg; i++) {
+                const int x = v2c[g->transpose[b + i]], a = x < 0 ? -x : x;
+                sign ^= x < 0;
+                const int t = a < min2 ? a : min2;
+                min2 = t > min1 ? t : min1;
+                min1 = t < min1 ? t : min1;
+            }
+            const int n1 = i8_norm(min1, rule, p), n2 = i8_norm(min2, rule, p);
+            for (int i = 0; i < deg; i++) {
+                const int x = v2c[g->transpose[b + i]], a = x < 0 ? -x : x;
+                const int mag = (a == min1) ? n2 : n1;
+                c2v[g->transpose[b + i]] = (sign ^ (x < 0)) ? -mag : mag;
+            }
+        }
+        if (enable_syndrome && ite != n_ite - 1) {
+            for (int v = 0; v < N; v++) {
+                int sum = 0;
+                for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+                post[v] = Yq[v] + sum;
+            }
+            const int z = i8_syndrome_is_zero(g, post, target);
+            cur_depth = z ? (cur_depth + 1) % syndrome_depth : 0;
+            if (z && cur_depth == 0) { ite++; return ite; }
+        }
+    }
+    for (int v = 0; v < N; v++) {
+        int sum = 0;
+        for (int e = g->vn_ptr[v]; e < g->vn_ptr[v + 1]; e++) sum += c2v[e];
+        post[v] = Yq[v] + sum;
+    }
+    return ite;
+}
+
+int orc_decode_i8(const orc_graph *g, int rule, float rule_param, float quant_scale, int n_ite, int enable_syndrome, int syndrome_depth,
+                  const float *Y_N, const int *target, int n_frames, float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
+{
+    if (!g || !Y_N || n_frames < 0 || n_ite < 0) return -1;
+    if (rule < ORC_RULE_MS || rule > ORC_RULE_NMS) return -2;
+    if (syndrome_depth < 1) syndrome_depth = 1;
+    int p = 0;
+    if (rule == ORC_RULE_OMS) p = (int)lrintf(rule_param * quant_scale);
+    if (rule == ORC_RULE_NMS) p = (int)lrintf(rule_param * 128.0f);
+    if (p < 0) p = 0;
+    if (p > 128) p = 128;
+    const int N = g->N, E = g->E;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        int *yq = (int *)malloc(sizeof(int) * (size_t)N * 2);
+        int *post = yq + N;
+        int *a = (int *)malloc(sizeof(int) * (size_t)E * 2);
+        int *b = a + E;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int f = 0; f < n_frames; f++) {
+            const int *tg = target ? target + (size_t)f * g->M : 0;
+            for (int v = 0; v < N; v++) yq[v] = i8_quant(Y_N[(size_t)f * N + v], quant_scale);
+            const int it = decode_flooding_i8(g, rule, p, n_ite, enable_syndrome, syndrome_depth, yq, tg, post, a, b);
+            if (post_out) for (int v = 0; v < N; v++) post_out[(size_t)f * N + v] = (float)post[v];
+            if (hard) for (int v = 0; v < N; v++) hard[(size_t)f * N + v] = post[v] < 0;
+            if (iters) iters[f] = it;
+            if (synd_ok) synd_ok[f] = i8_syndrome_is_zero(g, post, tg);
+        }
+        free(yq); free(a);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------- privacy amplification ----- */
 
 /* rnd_getPrngValue2_32 (EC/subcomponents/rnd.c:118-127): 32 x { b = parity(state & 0xe0000200); state <<= 1; state += b } */

@@ -19,6 +19,7 @@
 #include "qldpc_graph.h"
 #include "qldpc_kernels.h"
 #include "qldpc_kernels_edge.h"
+#include "qldpc_kernels_i8.h"
 
 #define HIPCHK(expr)                                                                                    \
     do {                                                                                                \
@@ -72,6 +73,9 @@ struct qldpc_decoder {
     int has_synd;
     float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
+    int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */
+    uint32_t *d_llr8;                /* [G][N][256] quantised channel LLRs, four frames of a lane per dword */
+    float quant_scale;
     int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
     /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
     int engine, eW, eS, e_stride;
@@ -151,7 +155,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
-    (void)hipFree(d->d_llr); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
+    (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
@@ -176,6 +180,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     int V = cfg->frames_per_lane;
     if (V == 0) V = (cfg->msg_dtype == 1) ? 2 : 1;      /* fp16 storage: 2 frames per lane keep the rows at 256 bytes; measured on MI355X: 256-byte rows (V = 1) are 2-5 % faster than V = 2 / 4 at every batch size, and exit earlier */
     if (const char *e = getenv("QLDPC_FRAMES_PER_LANE")) { int x = atoi(e); if (x == 1 || x == 2 || x == 4) V = x; }
+    if (cfg->msg_dtype == 2) V = QI_V;                   /* 8-bit messages: the four frames of a lane are the four bytes of a dword */
     d->V = V; d->FG = 64 * V; d->G = (cfg->max_frames + d->FG - 1) / d->FG;
     d->freeze = cfg->freeze_messages ? 1 : 0;
     if (const char *e = getenv("QLDPC_FREEZE")) d->freeze = atoi(e) ? 1 : 0;
@@ -217,6 +222,18 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         d->engine = eng;
         d->msg_half = cfg->msg_dtype == 1;
         if (const char *e = getenv("QLDPC_MSG_HALF")) d->msg_half = atoi(e) ? 1 : 0;
+        d->msg_i8 = cfg->msg_dtype == 2;
+        d->quant_scale = cfg->quant_scale > 0.0f ? cfg->quant_scale : 4.0f;
+        if (d->msg_i8) {
+            if (cfg->schedule != QLDPC_SCHED_FLOODING || cfg->rule > QLDPC_RULE_NMS || cfg->engine == QLDPC_ENGINE_EDGES || cfg->freeze_messages ||
+                (cfg->frames_per_lane != 0 && cfg->frames_per_lane != QI_V)) {
+                qldpc_set_error("8-bit messages are implemented for flooding MS/OMS/NMS on the FRAMES engine (frames_per_lane 0 or 4, freeze_messages 0)");
+                return QLDPC_EUNSUPPORTED;
+            }
+            if (code->max_dv > 256) { qldpc_set_error("8-bit messages: VN degree %d > 256 would overflow the 16-bit posterior", code->max_dv); return QLDPC_EUNSUPPORTED; }
+            d->engine = eng = QLDPC_ENGINE_FRAMES;
+            d->msg_half = 0;
+        }
         if (d->msg_half && (eng != QLDPC_ENGINE_FRAMES || cfg->schedule != QLDPC_SCHED_FLOODING)) {
             if (cfg->engine == QLDPC_ENGINE_AUTO && cfg->schedule == QLDPC_SCHED_FLOODING) d->engine = QLDPC_ENGINE_FRAMES;
             else { qldpc_set_error("fp16 message storage is implemented for the flooding schedule on the FRAMES engine"); return QLDPC_EUNSUPPORTED; }
@@ -260,7 +277,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
     if ((rc = dev_alloc(d, &d->d_llr, G * d->N * FG))) return rc;
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
-        const size_t elems = d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG;      /* floats of storage */
+        const size_t elems = d->msg_i8 ? (G * d->E * FG + 3) / 4 : (d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG);      /* floats of storage */
+        if (d->msg_i8 && (rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
         if ((rc = dev_alloc(d, &d->d_a, elems))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, elems))) return rc;
     } else {
@@ -291,6 +309,8 @@ extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *in
     if (cfg->schedule != QLDPC_SCHED_FLOODING && cfg->schedule != QLDPC_SCHED_HLAYERED) { qldpc_set_error("decoder_create: schedule=%d", cfg->schedule); return QLDPC_EINVAL; }
     if (cfg->enable_syndrome && cfg->syndrome_depth < 1) { qldpc_set_error("decoder_create: syndrome_depth=%d", cfg->syndrome_depth); return QLDPC_EINVAL; }
     if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 && cfg->frames_per_lane != 4) { qldpc_set_error("decoder_create: frames_per_lane=%d", cfg->frames_per_lane); return QLDPC_EINVAL; }
+    if (cfg->msg_dtype < 0 || cfg->msg_dtype > 2) { qldpc_set_error("decoder_create: msg_dtype=%d", cfg->msg_dtype); return QLDPC_EINVAL; }
+    if (!(cfg->quant_scale >= 0.0f) || cfg->quant_scale > 64.0f) { qldpc_set_error("decoder_create: quant_scale=%g", (double)cfg->quant_scale); return QLDPC_EINVAL; }
     qldpc_decoder *d = new (std::nothrow) qldpc_decoder();
     if (!d) return QLDPC_ENOMEM;
     int rc = create_impl(code, K, info_bits_pos, cfg, d);
@@ -402,6 +422,17 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
 {
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    if (d->msg_i8) {
+        if constexpr (V == QI_V && FAM == QK_FAM_MS) {
+            qi_rule qr{d->cfg.rule, 0};
+            if (d->cfg.rule == QLDPC_RULE_OMS) qr.param = (int)lrintf(d->cfg.rule_param * d->quant_scale);
+            if (d->cfg.rule == QLDPC_RULE_NMS) qr.param = (int)lrintf(d->cfg.rule_param * 128.0f);
+            qr.param = std::min(128, std::max(0, qr.param));
+            hipLaunchKernelGGL((qi_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
+                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qr, d->has_synd ? d->d_synd : nullptr, d->M);
+        }
+        return;
+    }
     if (d->msg_half)
         hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
                            d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
@@ -472,6 +503,14 @@ template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
 {
     constexpr int UN = (CAP > 0 && CAP <= 4) ? 4 : 2;
+    if (d->msg_i8) {
+        if constexpr (V == QI_V) {
+            dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
+            hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, d->d_hard,
+                               post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done);
+        }
+        return;
+    }
     if (d->msg_half) launch_vn_k<V, CAP, UN, MODE, __half>(d, b, post_out);
     else launch_vn_k<V, CAP, UN, MODE, float>(d, b, post_out);
 }
@@ -487,13 +526,14 @@ static void launch_vn(qldpc_decoder *d, const bucket &b, float *post_out)
 }
 
 /* algorithmic bytes: only live (non-padding) frames are counted */
-static double msg_b(const qldpc_decoder *d) { return d->msg_half ? 2.0 : 4.0; }
+static double msg_b(const qldpc_decoder *d) { return d->msg_i8 ? 1.0 : (d->msg_half ? 2.0 : 4.0); }
+static double llr_b(const qldpc_decoder *d) { return d->msg_i8 ? 1.0 : 4.0; }
 static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * msg_b(d) * d->n_frames; }
 static double bytes_vn(const qldpc_decoder *d, int mode)
 {
-    if (mode == QK_VN_FIRST) return ((double)d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
-    if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
-    return (2.0 * d->E * msg_b(d) + d->N * 4.0) * d->n_frames;
+    if (mode == QK_VN_FIRST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
+    if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
+    return (2.0 * d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
 }
 static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * 4.0 * d->n_frames; }
 
@@ -803,6 +843,11 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
         default: hipLaunchKernelGGL((qk_load_llr<4>), grid, dim3(256), 0, d->stream, d_llr, d->d_llr, d->N, n_frames); break;
         }
         LAUNCHCHK();
+        if (d->msg_i8) {
+            const size_t n_dwords = (size_t)d->G * d->N * 64;
+            hipLaunchKernelGGL(qi_quant_llr, dim3((unsigned)std::min<size_t>((n_dwords + 255) / 256, 16384)), dim3(256), 0, d->stream, d->d_llr, d->d_llr8, n_dwords, d->quant_scale);
+            LAUNCHCHK();
+        }
     }
     d->loaded = 1; d->ran = 0;
     return QLDPC_OK;
@@ -834,6 +879,11 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
         default: hipLaunchKernelGGL((qk_load_bits<4>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
         }
         LAUNCHCHK();
+        if (d->msg_i8) {
+            const size_t n_dwords = (size_t)d->G * d->N * 64;
+            hipLaunchKernelGGL(qi_quant_llr, dim3((unsigned)std::min<size_t>((n_dwords + 255) / 256, 16384)), dim3(256), 0, d->stream, d->d_llr, d->d_llr8, n_dwords, d->quant_scale);
+            LAUNCHCHK();
+        }
     }
     d->loaded = 1; d->ran = 0;
     return QLDPC_OK;

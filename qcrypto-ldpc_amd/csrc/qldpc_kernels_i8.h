@@ -1,0 +1,281 @@
+/*
+ * qldpc_kernels_i8.h -- 8-bit fixed-point variant of the flooding min-sum kernels (qldpc_decoder_cfg.msg_dtype = 2).
+ *
+ * Same frame-interleaved layout as qldpc_kernels.h with FOUR frames per wavefront lane (V = 4, FG = 256): a lane's
+ * four messages of one edge are the four bytes of one dword, so a row is still 256 bytes and every HBM byte carries a
+ * message.  A quarter of the fp32 bytes per iteration ("int8 quarters A_iter").
+ *
+ * Arithmetic (integer, therefore order-free and bit-exact against oracle/qldpc_oracle.c:decode_flooding_i8):
+ *   Yq        = clamp(rint(LLR * quant_scale), -127, 127)                      (qi_quant_llr)
+ *   tmp       = Yq + sum of chk_to_var over the VN's slots                     (16-bit, cannot overflow for dv <= 256)
+ *   var_to_chk= clamp(tmp - chk_to_var, -127, 127)
+ *   check fold: min1 / min2 of |var_to_chk|, sign = xor of (var_to_chk < 0) [xor target syndrome];
+ *               MS: n = m; OMS: n = max(0, m - rint(offset * quant_scale)); NMS: n = (m * rint(factor * 128)) >> 7
+ *   chk_to_var= +-(|var_to_chk| == min1 ? n(min2) : n(min1))
+ *   decision  = tmp < 0 (an integer has no -0, so signbit(post) and !(post >= 0) coincide)
+ * The structure follows the saturating fixed-point min-sum the reference keeps in MATLAB
+ * (ldpc_examples/.../BPSK_nrldpc_sim_RM_FP.m:37-98: quantise, subtract, saturate, min1/min2/parity, offset, saturate),
+ * carried over to AFF3CT's flooding schedule.  FER-tolerance class against the float decoder.
+ *
+ * The four bytes are widened to two packed-int16 registers (v_perm_b32 with its sign-extension selectors) and all
+ * arithmetic is v_pk_*_{i16,u16}: two frames per VALU lane-operation, which keeps the kernel HBM-bound.
+ */
+#ifndef QLDPC_KERNELS_I8_H
+#define QLDPC_KERNELS_I8_H
+
+#include "qldpc_kernels.h"
+
+typedef short qi_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short qi_u2 __attribute__((ext_vector_type(2)));
+
+#define QI_V 4
+#define QI_FG 256
+
+__device__ __forceinline__ qi_s2 qi_as_s2(uint32_t w) { return __builtin_bit_cast(qi_s2, w); }
+__device__ __forceinline__ qi_u2 qi_as_u2(qi_s2 x) { return __builtin_bit_cast(qi_u2, x); }
+__device__ __forceinline__ qi_s2 qi_as_s2(qi_u2 x) { return __builtin_bit_cast(qi_s2, x); }
+__device__ __forceinline__ uint32_t qi_as_u32(qi_s2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ qi_s2 qi_splat(int v) { qi_s2 r; r.x = (short)v; r.y = (short)v; return r; }
+
+/* bytes {b0,b1,b2,b3} of w (signed) -> lo = {b0,b1}, hi = {b2,b3} as packed int16.  v_perm_b32 picks bytes out of
+ * {S0 = w << 8 (bytes 4..7), S1 = w (bytes 0..3)}; selectors 8..11 give the sign of bytes 1, 3, 5, 7 replicated. */
+__device__ __forceinline__ void qi_unpack(uint32_t w, qi_s2 &lo, qi_s2 &hi)
+{
+    const uint32_t s = w << 8;
+    lo = qi_as_s2(__builtin_amdgcn_perm(s, w, 0x08010a00u));      /* b0, sign(b0 = byte 5), b1, sign(b1 = byte 1) */
+    hi = qi_as_s2(__builtin_amdgcn_perm(s, w, 0x09030b02u));      /* b2, sign(b2 = byte 7), b3, sign(b3 = byte 3) */
+}
+__device__ __forceinline__ uint32_t qi_pack(qi_s2 lo, qi_s2 hi)
+{
+    return __builtin_amdgcn_perm(qi_as_u32(hi), qi_as_u32(lo), 0x06040200u);
+}
+__device__ __forceinline__ uint32_t qi_ldm(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void qi_stm(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
+__device__ __forceinline__ qi_s2 qi_abs(qi_s2 x) { return __builtin_elementwise_max(x, (qi_s2)(-x)); }
+__device__ __forceinline__ qi_s2 qi_clamp127(qi_s2 x) { return __builtin_elementwise_max(__builtin_elementwise_min(x, qi_splat(127)), qi_splat(-127)); }
+
+struct qi_rule {
+    int rule;       /* 0 MS, 1 OMS, 2 NMS */
+    int param;      /* OMS: offset in quantiser steps; NMS: factor * 128 */
+};
+
+/* magnitudes after the rule, two frames at once (0 <= m <= 127) */
+__device__ __forceinline__ qi_s2 qi_norm(qi_s2 m, const qi_rule &r)
+{
+    if (r.rule == 0) return m;
+    const qi_u2 p = qi_as_u2(qi_splat(r.param));
+    if (r.rule == 1) return qi_as_s2(__builtin_elementwise_sub_sat(qi_as_u2(m), p));
+    return qi_as_s2((qi_u2)((qi_u2)(qi_as_u2(m) * p) >> 7));
+}
+
+/* one pair of frames of one check */
+struct qi_acc {
+    qi_s2 sg, m1, m2, n1, dn;
+    __device__ __forceinline__ void begin(unsigned s0, unsigned s1)
+    {
+        sg.x = (short)(s0 << 15); sg.y = (short)(s1 << 15);
+        m1 = qi_splat(127); m2 = qi_splat(127);
+    }
+    __device__ __forceinline__ void in(qi_s2 x)
+    {
+        const qi_s2 a = qi_abs(x);
+        sg ^= x;
+        const qi_s2 t = __builtin_elementwise_min(a, m2);
+        m2 = __builtin_elementwise_max(t, m1);
+        m1 = __builtin_elementwise_min(t, m1);
+    }
+    __device__ __forceinline__ void finish(const qi_rule &r)
+    {
+        n1 = qi_norm(m1, r);
+        dn = qi_norm(m2, r) - n1;
+    }
+    __device__ __forceinline__ qi_s2 out(qi_s2 x) const
+    {
+        const qi_s2 a = qi_abs(x);
+        /* ind = 1 iff a < m2, i.e. this edge holds the unique minimum; a is either == m1 or >= m2 */
+        const qi_u2 ind = __builtin_elementwise_min(__builtin_elementwise_sub_sat(qi_as_u2(m2), qi_as_u2(a)), qi_as_u2(qi_splat(1)));
+        const qi_s2 mag = n1 + qi_as_s2((qi_u2)(ind * qi_as_u2(dn)));
+        const qi_s2 s = (qi_s2)(sg ^ x) >> 15;                 /* 0 or -1 */
+        return (qi_s2)(mag ^ s) - s;
+    }
+};
+
+/* ------------------------------------------------------------------ check nodes -------------- */
+
+template <int DCMAX>
+__global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__restrict__ v2c, uint32_t *__restrict__ c2v,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                                          size_t group_stride /* dwords */, const u64 *__restrict__ done, qi_rule rule,
+                                                          const u64 *__restrict__ synd, int M)
+{
+    const int g = blockIdx.y;
+    if (qk_group_done<QI_V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * QK_WAVES + wave;
+    if (i >= n_list) return;
+    const uint32_t *vin = v2c + (size_t)g * group_stride + lane;
+    uint32_t *cout = c2v + (size_t)g * group_stride + lane;
+    const int c = list[i];
+    const int b = cn_ptr[c];
+    const int deg = cn_ptr[c + 1] - b;
+    qi_acc lo, hi;
+    {
+        unsigned s[QI_V] = {0, 0, 0, 0};
+        if (synd) {
+#pragma unroll
+            for (int j = 0; j < QI_V; j++) s[j] = (unsigned)((synd[((size_t)g * M + c) * QI_V + j] >> lane) & 1ull);
+        }
+        lo.begin(s[0], s[1]); hi.begin(s[2], s[3]);
+    }
+    if constexpr (DCMAX > 0) {
+        int slot[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++) slot[k] = cn_tr[b + k];
+        uint32_t w[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) w[k] = qi_ldm(vin + (size_t)slot[k] * 64);
+        qi_s2 xl[DCMAX], xh[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) { qi_unpack(w[k], xl[k], xh[k]); lo.in(xl[k]); hi.in(xh[k]); }
+        lo.finish(rule); hi.finish(rule);
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) qi_stm(cout + (size_t)slot[k] * 64, qi_pack(lo.out(xl[k]), hi.out(xh[k])));
+    } else {
+        for (int k = 0; k < deg; k++) {
+            qi_s2 xl, xh;
+            qi_unpack(vin[(size_t)cn_tr[b + k] * 64], xl, xh);
+            lo.in(xl); hi.in(xh);
+        }
+        lo.finish(rule); hi.finish(rule);
+        for (int k = 0; k < deg; k++) {
+            const size_t off = (size_t)cn_tr[b + k] * 64;
+            qi_s2 xl, xh;
+            qi_unpack(vin[off], xl, xh);
+            cout[off] = qi_pack(lo.out(xl), hi.out(xh));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ variable nodes ----------- */
+
+template <int DVMAX, int UN, int MODE>
+__global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__restrict__ c2v, const uint32_t *__restrict__ llr8,
+                                                          uint32_t *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
+                                                          float *__restrict__ post_out,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ vn_ptr, int N, size_t group_stride /* dwords */,
+                                                          const u64 *__restrict__ done)
+{
+    const int g = blockIdx.y;
+    if (MODE != QK_VN_POST && qk_group_done<QI_V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t *cin = c2v + (size_t)g * group_stride + lane;
+    uint32_t *vout = v2c + (size_t)g * group_stride + lane;
+    const uint32_t *yin = llr8 + (size_t)g * N * 64 + lane;
+    const int i0 = (blockIdx.x * QK_WAVES + wave) * UN;
+    if (i0 >= n_list) return;
+
+    int vv[UN], bb[UN], dd[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const int i = (i0 + u < n_list) ? i0 + u : i0;      /* the tail repeats entry i0 (idempotent) */
+        vv[u] = list[i];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
+    uint32_t y[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) y[u] = qi_ldm(yin + (size_t)vv[u] * 64);
+    qi_s2 tl[UN], th[UN];
+
+    if constexpr (MODE == QK_VN_FIRST) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            qi_unpack(y[u], tl[u], th[u]);
+            for (int k = 0; k < dd[u]; k++) qi_stm(vout + (size_t)(bb[u] + k) * 64, y[u]);     /* |Yq| <= 127 already */
+        }
+    } else if constexpr (DVMAX > 0) {
+        uint32_t m[UN][DVMAX];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++)
+                if (k < dd[u]) m[u][k] = qi_ldm(cin + (size_t)(bb[u] + k) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            qi_s2 ml[DVMAX], mh[DVMAX];
+            qi_unpack(y[u], tl[u], th[u]);
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++)
+                if (k < dd[u]) { qi_unpack(m[u][k], ml[k], mh[k]); tl[u] += ml[k]; th[u] += mh[k]; }
+            if constexpr (MODE == QK_VN_NORMAL) {
+#pragma unroll
+                for (int k = 0; k < DVMAX; k++)
+                    if (k < dd[u]) qi_stm(vout + (size_t)(bb[u] + k) * 64, qi_pack(qi_clamp127(tl[u] - ml[k]), qi_clamp127(th[u] - mh[k])));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            qi_unpack(y[u], tl[u], th[u]);
+            for (int k = 0; k < dd[u]; k++) {
+                qi_s2 ml, mh;
+                qi_unpack(cin[(size_t)(bb[u] + k) * 64], ml, mh);
+                tl[u] += ml; th[u] += mh;
+            }
+            if constexpr (MODE == QK_VN_NORMAL) {
+                for (int k = 0; k < dd[u]; k++) {
+                    qi_s2 ml, mh;
+                    qi_unpack(cin[(size_t)(bb[u] + k) * 64], ml, mh);
+                    qi_stm(vout + (size_t)(bb[u] + k) * 64, qi_pack(qi_clamp127(tl[u] - ml), qi_clamp127(th[u] - mh)));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        const short t[QI_V] = {tl[u].x, tl[u].y, th[u].x, th[u].y};
+#pragma unroll
+        for (int j = 0; j < QI_V; j++) {
+            u64 s = __ballot(t[j] < 0);
+            const size_t bi = ((size_t)g * N + vv[u]) * QI_V + j;
+            const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * QI_V + j];
+            if (dm) s = (s & ~dm) | (sgn[bi] & dm);       /* converged frames keep the ballots they converged with */
+            if (lane == 0) { sgn[bi] = s; hard[bi] = s; }
+        }
+        if constexpr (MODE == QK_VN_POST) {
+            if (post_out) {
+                qk_f32x4 p;
+                p.x = (float)t[0]; p.y = (float)t[1]; p.z = (float)t[2]; p.w = (float)t[3];
+                *reinterpret_cast<qk_f32x4 *>(post_out + ((size_t)g * N + vv[u]) * QI_FG + lane * QI_V) = p;
+            }
+        }
+    }
+}
+
+/* channel LLRs [G][N][256] f32 -> [G][N][256] int8, four frames of a lane per dword */
+__global__ __launch_bounds__(256) void qi_quant_llr(const float *__restrict__ llr, uint32_t *__restrict__ llr8, size_t n_dwords, float scale)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) {
+        const qk_f32x4 v = *reinterpret_cast<const qk_f32x4 *>(llr + i * 4);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float t = f[j] * scale;
+            const int q = !(t < 127.0f) ? 127 : (t < -127.0f ? -127 : __float2int_rn(t));
+            w |= (uint32_t)(q & 0xff) << (8 * j);
+        }
+        llr8[i] = w;
+    }
+}
+
+#endif /* QLDPC_KERNELS_I8_H */
