@@ -12,6 +12,7 @@
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
  *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
  *                  [-d parity_ber (dirty disclosed parity bits, BS/data_dvb/data5)]
+ *                  [-Q 32|16|8 (message storage: fp32 = the AFF3CT float build, binary16, 8-bit fixed-point min-sum)]
  *                  [-e f (puncture parity bits to reach the rate min_cr(ber, f); random pattern re-drawn per batch, main.cpp:321-333,359-362)]
  */
 #include <math.h>
@@ -49,14 +50,14 @@ static int die(const char *what, int rc)
 
 int main(int argc, char **argv)
 {
-    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, opt;
+    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, msg_bits = 32, opt;
     double parity_ber = 0.0;      /* > 0: the disclosed parity bits are themselves wrong with this probability (main.cpp (test effect of dirty parities)) */
     double target_eff = 0.0;      /* > 0: puncture parity bits up to min_cr(ber, f), as BS/src/main.cpp:235-333 does */
     const char *alist = NULL, *qc = NULL, *rule_name = "NMS";
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:ln")) != -1) {
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:Q:ln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -72,6 +73,7 @@ int main(int argc, char **argv)
         case 'P': peg = atoi(optarg); break;
         case 'e': target_eff = atof(optarg); break;
         case 'd': parity_ber = atof(optarg); break;
+        case 'Q': msg_bits = atoi(optarg); break;
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -98,11 +100,13 @@ int main(int argc, char **argv)
     qldpc_decoder_cfg_default(&cfg);
     cfg.schedule = layered ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING;
     cfg.rule = rule; cfg.rule_param = param; cfg.n_ite = n_ite; cfg.enable_syndrome = synd; cfg.syndrome_depth = 1; cfg.max_frames = batch;
+    if (msg_bits != 32 && msg_bits != 16 && msg_bits != 8) { fprintf(stderr, "-Q 32 | 16 | 8\n"); return 2; }
+    cfg.msg_dtype = msg_bits == 16 ? 1 : (msg_bits == 8 ? 2 : 0);      /* 16: binary16 message storage; 8: fixed-point min-sum */
     qldpc_decoder *dec = NULL;
     if ((rc = qldpc_decoder_create(H, K, pos, &cfg, &dec))) return die("decoder", rc);
 
-    printf("# * libqldpc %d on HIP device 0; Decoder_LDPC_BP_%s_Update_rule_%s (param %g), n_ite %d, syndrome %d\n", qldpc_version(),
-           layered ? "horizontal_layered" : "flooding", rule_name, (double)param, n_ite, synd);
+    printf("# * libqldpc %d on HIP device 0; Decoder_LDPC_BP_%s_Update_rule_%s (param %g), n_ite %d, syndrome %d, %d-bit messages\n", qldpc_version(),
+           layered ? "horizontal_layered" : "flooding", rule_name, (double)param, n_ite, synd, msg_bits);
     printf("#    ** Info. bits (K) = %d\n#    ** Frame size (N) = %d\n#    ** Code rate  (R) = %f\n#    ** max CN degree   = %d\n", K, N, (double)K / N, qldpc_code_max_cn_degree(H));
     printf("#    ** Est. QKD Key Rate After Priv Amp = %f\n", (double)(K - (N - K)) / (double)K);
     printf("# %8s | %8s | %8s | %8s | %9s | %9s | %10s\n", "EP", "FRA", "BE", "FE", "BER", "FER", "SIM_THR");
