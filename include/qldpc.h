@@ -158,7 +158,8 @@ typedef struct qldpc_decoder_cfg {
                             binary16 in HBM, fp32 arithmetic (half the bytes per iteration; FER-tolerance class against
                             AFF3CT, bit-exact against the oracle run with the same rounding; FRAMES engine, flooding);
                             2 = 8-bit fixed point: channel LLRs quantised to clamp(rint(LLR * quant_scale), +-127), messages
-                            saturating at +-127, integer min-sum (MS / OMS / NMS, flooding, FRAMES engine, 4 frames per lane):
+                            saturating at +-127, integer min-sum (MS / OMS / NMS; flooding, or horizontal layered with the posterior
+                            kept in 8 bits as well; FRAMES engine, 4 frames per lane):
                             a quarter of the bytes per iteration, FER-tolerance class against AFF3CT, bit-exact against the
                             oracle's integer decoder; qldpc_fetch_post_dev then returns the integer posteriors           */
     float quant_scale;   /* msg_dtype 2: quantiser steps per LLR unit (0 = 4.0); OMS offset = rint(rule_param * quant_scale)

@@ -54,7 +54,7 @@ def lib():
         L.orc_decode_coset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
                                        fp, ip, ip, ip, C.c_int]
         L.orc_decode_i8.restype = C.c_int
-        L.orc_decode_i8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
+        L.orc_decode_i8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int,
                                     fp, ip, ip, ip, C.c_int]
         L.orc_syndrome.restype = C.c_int
         L.orc_syndrome.argtypes = [C.c_void_p, ip, ip]
@@ -145,8 +145,8 @@ def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", ena
     if target is not None:
         tgt = np.ascontiguousarray(target, dtype=np.int32).reshape(F, graph.M)
     if msg_i8:
-        assert schedule == "flooding" and not msg_fp16
-        rc = lib().orc_decode_i8(graph._h, RULES[rule], float(param), float(quant_scale), int(n_ite), int(enable_syndrome), int(syndrome_depth),
+        assert not msg_fp16
+        rc = lib().orc_decode_i8(graph._h, SCHEDULES[schedule], RULES[rule], float(param), float(quant_scale), int(n_ite), int(enable_syndrome), int(syndrome_depth),
                                  _fp(llr), _ip(tgt) if tgt is not None else None, F, _fp(post), _ip(hard), _ip(iters), _ip(ok), int(n_threads))
         if rc != 0:
             raise RuntimeError("orc_decode_i8 failed: %d" % rc)

@@ -586,11 +586,53 @@ static int decode_flooding_i8(const orc_graph *g, int rule, int p, int n_ite, in
     return ite;
 }
 
-int orc_decode_i8(const orc_graph *g, int rule, float rule_param, float quant_scale, int n_ite, int enable_syndrome, int syndrome_depth,
+/* Fixed-point horizontal layered sweep, posterior kept in 8 bits: the recursion of BPSK_nrldpc_sim_RM_FP.m:50-93
+ * (L = L - R; saturate; min-sum; R = new; L = saturate(L + R)) with one check per layer row, syndrome test after every
+ * iteration as decode_hlayered. */
+static int decode_hlayered_i8(const orc_graph *g, int rule, int p, int n_ite, int enable_syndrome, int syndrome_depth,
+                              const int *Yq, const int *target, int *post, int *msg, int *contr)
+{
+    const int N = g->N, M = g->M, E = g->E;
+    memcpy(post, Yq, sizeof(int) * (size_t)N);
+    memset(msg, 0, sizeof(int) * (size_t)E);
+    int cur_depth = 0, ite = 0;
+    for (; ite < n_ite; ite++) {
+        for (int c = 0; c < M; c++) {
+            const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
+            int sign = target ? (target[c] & 1) : 0, min1 = 127, min2 = 127;
+            for (int i = 0; i < deg; i++) {
+                contr[i] = post[g->cn_var[b + i]] - msg[b + i];
+                const int x = contr[i] > 127 ? 127 : (contr[i] < -127 ? -127 : contr[i]), a = x < 0 ? -x : x;
+                sign ^= x < 0;
+                const int t = a < min2 ? a : min2;
+                min2 = t > min1 ? t : min1;
+                min1 = t < min1 ? t : min1;
+            }
+            const int n1 = i8_norm(min1, rule, p), n2 = i8_norm(min2, rule, p);
+            for (int i = 0; i < deg; i++) {
+                const int x = contr[i] > 127 ? 127 : (contr[i] < -127 ? -127 : contr[i]), a = x < 0 ? -x : x;
+                const int mag = (a == min1) ? n2 : n1;
+                const int out = (sign ^ (x < 0)) ? -mag : mag;
+                msg[b + i] = out;
+                const int np = contr[i] + out;
+                post[g->cn_var[b + i]] = np > 127 ? 127 : (np < -127 ? -127 : np);
+            }
+        }
+        if (enable_syndrome) {
+            const int z = i8_syndrome_is_zero(g, post, target);
+            cur_depth = z ? (cur_depth + 1) % syndrome_depth : 0;
+            if (z && cur_depth == 0) { ite++; return ite; }
+        }
+    }
+    return ite;
+}
+
+int orc_decode_i8(const orc_graph *g, int schedule, int rule, float rule_param, float quant_scale, int n_ite, int enable_syndrome, int syndrome_depth,
                   const float *Y_N, const int *target, int n_frames, float *post_out, int *hard, int *iters, int *synd_ok, int n_threads)
 {
     if (!g || !Y_N || n_frames < 0 || n_ite < 0) return -1;
     if (rule < ORC_RULE_MS || rule > ORC_RULE_NMS) return -2;
+    if (schedule != ORC_SCHED_FLOODING && schedule != ORC_SCHED_HLAYERED) return -3;
     if (syndrome_depth < 1) syndrome_depth = 1;
     int p = 0;
     if (rule == ORC_RULE_OMS) p = (int)lrintf(rule_param * quant_scale);
@@ -605,15 +647,16 @@ int orc_decode_i8(const orc_graph *g, int rule, float rule_param, float quant_sc
     {
         int *yq = (int *)malloc(sizeof(int) * (size_t)N * 2);
         int *post = yq + N;
-        int *a = (int *)malloc(sizeof(int) * (size_t)E * 2);
-        int *b = a + E;
+        int *a = (int *)malloc(sizeof(int) * ((size_t)E * 2 + (size_t)g->max_dc + 1));
+        int *b = a + E, *contr = b + E;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
         for (int f = 0; f < n_frames; f++) {
             const int *tg = target ? target + (size_t)f * g->M : 0;
             for (int v = 0; v < N; v++) yq[v] = i8_quant(Y_N[(size_t)f * N + v], quant_scale);
-            const int it = decode_flooding_i8(g, rule, p, n_ite, enable_syndrome, syndrome_depth, yq, tg, post, a, b);
+            const int it = schedule == ORC_SCHED_FLOODING ? decode_flooding_i8(g, rule, p, n_ite, enable_syndrome, syndrome_depth, yq, tg, post, a, b)
+                                                          : decode_hlayered_i8(g, rule, p, n_ite, enable_syndrome, syndrome_depth, yq, tg, post, a, contr);
             if (post_out) for (int v = 0; v < N; v++) post_out[(size_t)f * N + v] = (float)post[v];
             if (hard) for (int v = 0; v < N; v++) hard[(size_t)f * N + v] = post[v] < 0;
             if (iters) iters[f] = it;

@@ -80,9 +80,9 @@ int orc_decode_coset(const orc_graph *g, int schedule, int rule, float rule_para
                      int enable_syndrome, int syndrome_depth, const float *Y_N, const int *target, int n_frames,
                      float *post, int *hard, int *iters, int *synd_ok, int n_threads);
 
-/* 8-bit fixed-point flooding min-sum (rule MS / OMS / NMS only): channel LLRs quantised with quant_scale, messages
+/* 8-bit fixed-point min-sum, flooding or horizontal layered (rule MS / OMS / NMS only; layered keeps the posterior in 8 bits too): channel LLRs quantised with quant_scale, messages
  * saturating at +-127, integer arithmetic; target may be NULL (H x = 0).  post_out holds the integer posteriors as floats. */
-int orc_decode_i8(const orc_graph *g, int rule, float rule_param, float quant_scale, int n_ite, int enable_syndrome, int syndrome_depth,
+int orc_decode_i8(const orc_graph *g, int schedule, int rule, float rule_param, float quant_scale, int n_ite, int enable_syndrome, int syndrome_depth,
                   const float *Y_N, const int *target, int n_frames, float *post_out, int *hard, int *iters, int *synd_ok, int n_threads);
 
 /*

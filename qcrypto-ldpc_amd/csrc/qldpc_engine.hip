@@ -225,9 +225,9 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         d->msg_i8 = cfg->msg_dtype == 2;
         d->quant_scale = cfg->quant_scale > 0.0f ? cfg->quant_scale : 4.0f;
         if (d->msg_i8) {
-            if (cfg->schedule != QLDPC_SCHED_FLOODING || cfg->rule > QLDPC_RULE_NMS || cfg->engine == QLDPC_ENGINE_EDGES || cfg->freeze_messages ||
+            if (cfg->rule > QLDPC_RULE_NMS || cfg->engine == QLDPC_ENGINE_EDGES || cfg->freeze_messages ||
                 (cfg->frames_per_lane != 0 && cfg->frames_per_lane != QI_V)) {
-                qldpc_set_error("8-bit messages are implemented for flooding MS/OMS/NMS on the FRAMES engine (frames_per_lane 0 or 4, freeze_messages 0)");
+                qldpc_set_error("8-bit messages are implemented for MS/OMS/NMS on the FRAMES engine (frames_per_lane 0 or 4, freeze_messages 0)");
                 return QLDPC_EUNSUPPORTED;
             }
             if (code->max_dv > 256) { qldpc_set_error("8-bit messages: VN degree %d > 256 would overflow the 16-bit posterior", code->max_dv); return QLDPC_EUNSUPPORTED; }
@@ -281,6 +281,10 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         if (d->msg_i8 && (rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
         if ((rc = dev_alloc(d, &d->d_a, elems))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, elems))) return rc;
+    } else if (d->msg_i8) {
+        if ((rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
+        if ((rc = dev_alloc(d, &d->d_a, G * d->N * 64))) return rc;      /* post8 */
+        if ((rc = dev_alloc(d, &d->d_b, G * d->E * 64))) return rc;      /* msg8, CN-major */
     } else {
         if ((rc = dev_alloc(d, &d->d_a, G * d->N * FG))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
@@ -417,6 +421,16 @@ static int family_of(int rule)
     }
 }
 
+/* the rule in quantiser units (qldpc.h: quant_scale) */
+static qi_rule qi_rule_of(const qldpc_decoder *d)
+{
+    qi_rule qr{d->cfg.rule, 0};
+    if (d->cfg.rule == QLDPC_RULE_OMS) qr.param = (int)lrintf(d->cfg.rule_param * d->quant_scale);
+    if (d->cfg.rule == QLDPC_RULE_NMS) qr.param = (int)lrintf(d->cfg.rule_param * 128.0f);
+    qr.param = std::min(128, std::max(0, qr.param));
+    return qr;
+}
+
 template <int V, int CAP, int FAM>
 static void launch_cn_one(qldpc_decoder *d, const bucket &b)
 {
@@ -424,12 +438,8 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     if (d->msg_i8) {
         if constexpr (V == QI_V && FAM == QK_FAM_MS) {
-            qi_rule qr{d->cfg.rule, 0};
-            if (d->cfg.rule == QLDPC_RULE_OMS) qr.param = (int)lrintf(d->cfg.rule_param * d->quant_scale);
-            if (d->cfg.rule == QLDPC_RULE_NMS) qr.param = (int)lrintf(d->cfg.rule_param * 128.0f);
-            qr.param = std::min(128, std::max(0, qr.param));
             hipLaunchKernelGGL((qi_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
-                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qr, d->has_synd ? d->d_synd : nullptr, d->M);
+                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
         }
         return;
     }
@@ -467,6 +477,12 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
 {
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    if (d->msg_i8) {
+        if constexpr (V == QI_V && FAM == QK_FAM_MS)
+            hipLaunchKernelGGL((qi_cn_layer<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
+                               d->N, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
+        return;
+    }
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
                        d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
 }
@@ -535,7 +551,7 @@ static double bytes_vn(const qldpc_decoder *d, int mode)
     if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
     return (2.0 * d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
 }
-static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * 4.0 * d->n_frames; }
+static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * msg_b(d) * d->n_frames; }
 
 template <int V, int MODE>
 static int vn_pass(qldpc_decoder *d, float *post_out)
@@ -609,16 +625,22 @@ static int run_flooding(qldpc_decoder *d)
     return QLDPC_OK;
 }
 
+static int bx_of(const qldpc_decoder *d) { return std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, d->G))); }
+
 template <int V>
 static int run_layered(qldpc_decoder *d)
 {
     int rc;
     const int n_ite = d->cfg.n_ite;
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
-    HIPCHK(hipMemcpyAsync(d->d_a, d->d_llr, G * d->N * FG * sizeof(float), hipMemcpyDeviceToDevice, d->stream));   /* var_nodes = Y_N */
-    HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * sizeof(float), d->stream));                                     /* messages = 0   */
+    const size_t cell = d->msg_i8 ? 1 : sizeof(float);
+    HIPCHK(hipMemcpyAsync(d->d_a, d->msg_i8 ? (const void *)d->d_llr8 : (const void *)d->d_llr, G * d->N * FG * cell, hipMemcpyDeviceToDevice, d->stream));   /* var_nodes = Y_N */
+    HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));                                                                                       /* messages = 0   */
+    auto ballots = [&]() {
+        if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+        else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+    };
     int ite = 0;
-    const int bx = std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, d->G)));
     for (; ite < n_ite; ite++) {
         {
             prof_scope ps(d, KS_LAYER, bytes_layer(d));
@@ -626,7 +648,7 @@ static int run_layered(qldpc_decoder *d)
                 for (auto &b : d->layer_buckets[(size_t)l]) { launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
-            hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+            ballots();
             LAUNCHCHK();
             if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
             if ((rc = status_pass<V>(d, ite + 1))) return rc;
@@ -638,7 +660,7 @@ static int run_layered(qldpc_decoder *d)
         }
     }
     d->last_iters = std::min(ite, n_ite);
-    hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+    ballots();
     LAUNCHCHK();
     return QLDPC_OK;
 }
@@ -1018,6 +1040,12 @@ extern "C" int qldpc_fetch_post_dev(qldpc_decoder *d, float *d_post_out)
         default: rc = vn_pass<4, QK_VN_POST>(d, d->d_post); break;
         }
         if (rc) return rc;
+        src = d->d_post;
+    } else if (d->msg_i8) {
+        if (!d->d_post) { if ((rc = dev_alloc(d, &d->d_post, (size_t)d->G * d->N * d->FG))) return rc; }
+        const size_t n_dwords = (size_t)d->G * d->N * 64;
+        hipLaunchKernelGGL(qi_post_to_f32, dim3((unsigned)std::min<size_t>((n_dwords + 255) / 256, 16384)), dim3(256), 0, d->stream, (const uint32_t *)d->d_a, d->d_post, n_dwords);
+        LAUNCHCHK();
         src = d->d_post;
     } else {
         src = d->d_a;

@@ -15,7 +15,8 @@
  *   decision  = tmp < 0 (an integer has no -0, so signbit(post) and !(post >= 0) coincide)
  * The structure follows the saturating fixed-point min-sum the reference keeps in MATLAB
  * (ldpc_examples/.../BPSK_nrldpc_sim_RM_FP.m:37-98: quantise, subtract, saturate, min1/min2/parity, offset, saturate),
- * carried over to AFF3CT's flooding schedule.  FER-tolerance class against the float decoder.
+ * carried over to AFF3CT's flooding schedule (and, as qi_cn_layer, to its horizontal-layered one with the posterior
+ * itself kept in 8 bits, as the MATLAB decoder does).  FER-tolerance class against the float decoder.
  *
  * The four bytes are widened to two packed-int16 registers (v_perm_b32 with its sign-extension selectors) and all
  * arithmetic is v_pk_*_{i16,u16}: two frames per VALU lane-operation, which keeps the kernel HBM-bound.
@@ -258,6 +259,122 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
                 *reinterpret_cast<qk_f32x4 *>(post_out + ((size_t)g * N + vv[u]) * QI_FG + lane * QI_V) = p;
             }
         }
+    }
+}
+
+/* ------------------------------------------------------------------ horizontal layered ------- */
+
+/*
+ * One layer (VN-disjoint checks) of the fixed-point layered sweep -- the recursion of the reference's MATLAB decoder
+ * (BPSK_nrldpc_sim_RM_FP.m:50-93: L = L - R; saturate; min1/min2/parity; offset; R = new; L = saturate(L + R)) with
+ * one check row per "layer row", on the 8-bit containers:
+ *   contr = post[v] - msg[k]  (16-bit);  x = clamp(contr, +-127) enters the fold;  msg[k] = out;
+ *   post[v] = clamp(contr + out, +-127)
+ * post8 is [G][N][256] int8, msg8 is CN-major [G][E][256] int8.  One wavefront per check.
+ */
+template <int DCMAX>
+__global__ __launch_bounds__(QK_THREADS) void qi_cn_layer(uint32_t *__restrict__ post8, uint32_t *__restrict__ msg8,
+                                                          const int *__restrict__ list, int n_list,
+                                                          const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
+                                                          int N, size_t group_stride /* dwords */, const u64 *__restrict__ done, qi_rule rule,
+                                                          const u64 *__restrict__ synd, int M)
+{
+    const int g = blockIdx.y;
+    if (qk_group_done<QI_V>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * QK_WAVES + wave;
+    if (i >= n_list) return;
+    uint32_t *pg = post8 + (size_t)g * N * 64 + lane;
+    uint32_t *mg = msg8 + (size_t)g * group_stride + lane;
+    const int c = list[i];
+    const int b = cn_ptr[c];
+    const int deg = cn_ptr[c + 1] - b;
+    qi_acc lo, hi;
+    {
+        unsigned s[QI_V] = {0, 0, 0, 0};
+        if (synd) {
+#pragma unroll
+            for (int j = 0; j < QI_V; j++) s[j] = (unsigned)((synd[((size_t)g * M + c) * QI_V + j] >> lane) & 1ull);
+        }
+        lo.begin(s[0], s[1]); hi.begin(s[2], s[3]);
+    }
+    if constexpr (DCMAX > 0) {
+        int vn[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+        uint32_t pw[DCMAX], mw[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
+                pw[k] = pg[(size_t)vn[k] * 64];                   /* posteriors are re-read by later layers: cached */
+                mw[k] = qi_ldm(mg + (size_t)(b + k) * 64);        /* the check's own messages: read once, written once per sweep */
+            }
+        qi_s2 cl[DCMAX], ch[DCMAX];
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
+                qi_s2 pl, ph, ml, mh;
+                qi_unpack(pw[k], pl, ph); qi_unpack(mw[k], ml, mh);
+                cl[k] = pl - ml; ch[k] = ph - mh;
+                lo.in(qi_clamp127(cl[k])); hi.in(qi_clamp127(ch[k]));
+            }
+        lo.finish(rule); hi.finish(rule);
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++)
+            if (k < deg) {
+                const qi_s2 ol = lo.out(qi_clamp127(cl[k])), oh = hi.out(qi_clamp127(ch[k]));
+                qi_stm(mg + (size_t)(b + k) * 64, qi_pack(ol, oh));
+                pg[(size_t)vn[k] * 64] = qi_pack(qi_clamp127(cl[k] + ol), qi_clamp127(ch[k] + oh));
+            }
+    } else {
+        for (int k = 0; k < deg; k++) {
+            qi_s2 pl, ph, ml, mh;
+            qi_unpack(pg[(size_t)cn_var[b + k] * 64], pl, ph); qi_unpack(mg[(size_t)(b + k) * 64], ml, mh);
+            lo.in(qi_clamp127(pl - ml)); hi.in(qi_clamp127(ph - mh));
+        }
+        lo.finish(rule); hi.finish(rule);
+        for (int k = 0; k < deg; k++) {
+            qi_s2 pl, ph, ml, mh;
+            const size_t po = (size_t)cn_var[b + k] * 64, mo = (size_t)(b + k) * 64;
+            qi_unpack(pg[po], pl, ph); qi_unpack(mg[mo], ml, mh);
+            const qi_s2 cl = pl - ml, ch = ph - mh;
+            const qi_s2 ol = lo.out(qi_clamp127(cl)), oh = hi.out(qi_clamp127(ch));
+            mg[mo] = qi_pack(ol, oh);
+            pg[po] = qi_pack(qi_clamp127(cl + ol), qi_clamp127(ch + oh));
+        }
+    }
+}
+
+/* ballots of the 8-bit posterior array: sgn = hard = (post < 0); converged frames keep theirs */
+__global__ __launch_bounds__(QK_THREADS) void qi_post_ballots(const uint32_t *__restrict__ post8, u64 *__restrict__ sgn, u64 *__restrict__ hard,
+                                                              int N, const u64 *__restrict__ done)
+{
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int v = blockIdx.x * QK_WAVES + wave; v < N; v += gridDim.x * QK_WAVES) {
+        const uint32_t w = post8[((size_t)g * N + v) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < QI_V; j++) {
+            u64 s = __ballot((w >> (8 * j + 7)) & 1u);
+            const size_t bi = ((size_t)g * N + v) * QI_V + j;
+            const u64 dm = done[(size_t)g * QI_V + j];
+            if (dm) s = (s & ~dm) | (sgn[bi] & dm);
+            if (lane == 0) { sgn[bi] = s; hard[bi] = s; }
+        }
+    }
+}
+
+/* [G][N][256] int8 -> [G][N][256] f32 (posterior read-back) */
+__global__ __launch_bounds__(256) void qi_post_to_f32(const uint32_t *__restrict__ post8, float *__restrict__ dst, size_t n_dwords)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = post8[i];
+        qk_f32x4 p;
+        p.x = (float)(signed char)(w & 0xff); p.y = (float)(signed char)((w >> 8) & 0xff);
+        p.z = (float)(signed char)((w >> 16) & 0xff); p.w = (float)(signed char)(w >> 24);
+        *reinterpret_cast<qk_f32x4 *>(dst + i * 4) = p;
     }
 }
 

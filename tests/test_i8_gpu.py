@@ -154,8 +154,58 @@ def test_config2_code_sample_and_fer_class(q, O, torch):
 
 def test_unsupported_combinations_are_refused(q, gold):
     code = q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist"))
-    for kw in (dict(rule="SPA"), dict(schedule="hlayered", rule="NMS", rule_param=0.75), dict(rule="NMS", rule_param=0.75, engine="edges"),
+    for kw in (dict(rule="SPA"), dict(rule="NMS", rule_param=0.75, engine="edges"),
                dict(rule="NMS", rule_param=0.75, freeze_messages=True), dict(rule="NMS", rule_param=0.75, frames_per_lane=2)):
         with pytest.raises(q.QldpcError) as e:
             q.Decoder(code, 1008, 10, n_frames=4, msg_dtype="i8", **kw)
         assert e.value.status == -7                                         # QLDPC_EUNSUPPORTED
+
+
+def _layer_graph(O, code, og):
+    """the oracle sweeps checks 0..M-1; give it H with its rows in the product's layer order"""
+    order, _, _ = code.layer_order()
+    var, chk = og.edges()
+    inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+    newc = inv[chk]; idx = np.argsort(newc, kind="stable")
+    return O.Graph.from_edges(code.N, code.M, var[idx], newc[idx]), order
+
+
+@pytest.mark.parametrize("rule,param", [("OMS", 0.5), ("NMS", 0.75), ("MS", 0.0)])
+@pytest.mark.parametrize("synd", [False, True])
+def test_layered_fixed_point_bit_exact(q, O, torch, gold, rule, param, synd):
+    """horizontal layered with 8-bit posteriors and messages (the recursion of the reference's BPSK_nrldpc_sim_RM_FP.m)."""
+    p = os.path.join(gold, "PEGReg504x1008.alist")
+    code, og = q.Code.from_alist(p), O.Graph.from_alist(p)
+    og2, _ = _layer_graph(O, code, og)
+    F = 700
+    llr = bsc_frames(np.random.default_rng(21), F, 1008, 0.07, 2.6)
+    ref = O.decode(og2, llr, rule, param, 20, "hlayered", enable_syndrome=synd, n_threads=8, msg_i8=True, quant_scale=4.0)
+    dec = q.Decoder(code, 1008, 20, rule=rule, rule_param=param, n_frames=F, schedule="hlayered", enable_syndrome=synd, msg_dtype="i8")
+    hard, it, ok, post = run(q, torch, dec, llr, not synd)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    if not synd:
+        assert (post == ref["post"]).all() and np.abs(post).max() <= 127
+
+
+def test_layered_fixed_point_irregular_and_syndrome_form(q, O, torch):
+    code = q.Code.ira(4096, 3850, 0.4, 14, 4, 3)               # dc > 40: any-degree loop; colour-class layers
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    og2, order = _layer_graph(O, code, og)
+    rng = np.random.default_rng(9)
+    F = 260
+    x = rng.integers(0, 2, (F, code.N)).astype(np.uint8)
+    s = np.stack([og.syndrome(xx)[1] for xx in x])
+    y = x ^ (rng.random((F, code.N)) < 0.004)
+    mag = np.float32(q.bsc_llr(0.004))
+    llr = np.where(y == 1, -mag, mag).astype(np.float32)
+    ref = O.decode(og2, llr, "NMS", 0.75, 12, "hlayered", n_threads=8, target=s[:, order], msg_i8=True, quant_scale=4.0)
+    dec = q.Decoder(code, code.N, 12, rule="NMS", rule_param=0.75, n_frames=F, schedule="hlayered", msg_dtype="i8")
+    dec.load_bits(torch.from_numpy(i32(q.pack_bits(y))).cuda(), torch.full((F,), float(mag), device="cuda"))
+    dec.load_syndrome(torch.from_numpy(i32(q.pack_bits(s))).cuda())
+    dec.run()
+    hard = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), code.N)
+    it, ok = dec.fetch_status()
+    assert (hard == ref["hard"]).all() and (it.cpu().numpy() == ref["iters"]).all() and (ok.cpu().numpy() == ref["synd_ok"]).all()
+    good = ok.cpu().numpy() == 1
+    assert good.mean() > 0.2 and (hard[good] == x[good]).all()          # all N VNs are channel VNs here: a hard point for rate 0.94
