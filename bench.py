@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-message-storage variant leg")
     ap.add_argument("--no-int8", action="store_true", help="skip the 8-bit fixed-point variant leg")
+    ap.add_argument("--msg-dtype", default="f32", choices=["f32", "f16", "i8"], help="experiment: message storage of the main legs (the contract run uses f32)")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,7 +157,8 @@ def main():
     if rank == 0:
         log("frames ready: %d per GPU (%.1f s), code N=%d K=%d M=%d E=%d" % (F, time.time() - t0, N, K, code.M, code.E))
 
-    def make_decoder(enable_syndrome, msg_dtype="f32"):
+    def make_decoder(enable_syndrome, msg_dtype=None):
+        msg_dtype = msg_dtype or args.msg_dtype
         d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
                       n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype, schedule=args.schedule)
         d.set_stream(torch.cuda.current_stream(device))
@@ -212,6 +214,7 @@ def main():
     fer = 1.0 - good / n_all
     if args.schedule != "flooding":          # experiment mode: one kernel family, no CPU / fp16 legs
         kstats["cn_update"] = kstats["vn_update"] = kstats["layer_update"]
+    if args.schedule != "flooding" or args.msg_dtype != "f32":
         args.no_fp16 = args.no_int8 = args.no_cpu = True
     cn = kstats["cn_update"]
     vn = kstats["vn_update"]
@@ -310,7 +313,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "f16": "f32 (binary16 message storage)", "i8": "int8"}[args.msg_dtype],
             "data": "synthetic",
             "fer": fer,
             "iterations_executed": fixed_iters,

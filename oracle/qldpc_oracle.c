@@ -587,8 +587,8 @@ static int decode_flooding_i8(const orc_graph *g, int rule, int p, int n_ite, in
 }
 
 /* Fixed-point horizontal layered sweep, posterior kept in 8 bits: the recursion of BPSK_nrldpc_sim_RM_FP.m:50-93
- * (L = L - R; saturate; min-sum; R = new; L = saturate(L + R)) with one check per layer row, syndrome test after every
- * iteration as decode_hlayered. */
+ * (L = L - R; saturate to +-31 (maxqr); min-sum; R = new; L = saturate(L + R) to +-127 (maxqL)) with one check per layer
+ * row, syndrome test after every iteration as decode_hlayered. */
 static int decode_hlayered_i8(const orc_graph *g, int rule, int p, int n_ite, int enable_syndrome, int syndrome_depth,
                               const int *Yq, const int *target, int *post, int *msg, int *contr)
 {
@@ -599,10 +599,10 @@ static int decode_hlayered_i8(const orc_graph *g, int rule, int p, int n_ite, in
     for (; ite < n_ite; ite++) {
         for (int c = 0; c < M; c++) {
             const int b = g->cn_ptr[c], deg = g->cn_ptr[c + 1] - b;
-            int sign = target ? (target[c] & 1) : 0, min1 = 127, min2 = 127;
+            int sign = target ? (target[c] & 1) : 0, min1 = 31, min2 = 31;
             for (int i = 0; i < deg; i++) {
                 contr[i] = post[g->cn_var[b + i]] - msg[b + i];
-                const int x = contr[i] > 127 ? 127 : (contr[i] < -127 ? -127 : contr[i]), a = x < 0 ? -x : x;
+                const int x = contr[i] > 31 ? 31 : (contr[i] < -31 ? -31 : contr[i]), a = x < 0 ? -x : x;      /* maxqr = 31 */
                 sign ^= x < 0;
                 const int t = a < min2 ? a : min2;
                 min2 = t > min1 ? t : min1;
@@ -610,7 +610,7 @@ static int decode_hlayered_i8(const orc_graph *g, int rule, int p, int n_ite, in
             }
             const int n1 = i8_norm(min1, rule, p), n2 = i8_norm(min2, rule, p);
             for (int i = 0; i < deg; i++) {
-                const int x = contr[i] > 127 ? 127 : (contr[i] < -127 ? -127 : contr[i]), a = x < 0 ? -x : x;
+                const int x = contr[i] > 31 ? 31 : (contr[i] < -31 ? -31 : contr[i]), a = x < 0 ? -x : x;      /* maxqr = 31 */
                 const int mag = (a == min1) ? n2 : n1;
                 const int out = (sign ^ (x < 0)) ? -mag : mag;
                 msg[b + i] = out;
