@@ -20,6 +20,7 @@
 #include "qldpc_kernels.h"
 #include "qldpc_kernels_edge.h"
 #include "qldpc_kernels_i8.h"
+#include "qldpc_kernels_h16.h"
 
 #define HIPCHK(expr)                                                                                    \
     do {                                                                                                \
@@ -73,6 +74,7 @@ struct qldpc_decoder {
     int has_synd;
     float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
+    int packed_h16;                  /* binary16 variant: use the packed check-node kernel when V == 2 (QLDPC_PACKED_H16=0 turns it off) */
     int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */
     uint32_t *d_llr8;                /* [G][N][256] quantised channel LLRs, four frames of a lane per dword */
     float quant_scale;
@@ -222,6 +224,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         d->engine = eng;
         d->msg_half = cfg->msg_dtype == 1;
         if (const char *e = getenv("QLDPC_MSG_HALF")) d->msg_half = atoi(e) ? 1 : 0;
+        d->packed_h16 = 1;
+        if (const char *e = getenv("QLDPC_PACKED_H16")) d->packed_h16 = atoi(e) ? 1 : 0;
         d->msg_i8 = cfg->msg_dtype == 2;
         d->quant_scale = cfg->quant_scale > 0.0f ? cfg->quant_scale : 4.0f;
         if (d->msg_i8) {
@@ -442,6 +446,13 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
                                d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
         }
         return;
+    }
+    if (d->msg_half && !d->freeze && d->packed_h16) {
+        if constexpr (V == 2 && FAM == QK_FAM_MS && CAP > 0) {      /* packed binary16 fold (qldpc_kernels_h16.h), bit-identical */
+            hipLaunchKernelGGL((qh_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
+                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, r, d->has_synd ? d->d_synd : nullptr, d->M);
+            return;
+        }
     }
     if (d->msg_half)
         hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,

@@ -330,6 +330,25 @@ def test_default_mode_freezes_decisions_not_messages(q, O, torch, peg, sched, V)
     assert 0 < (ref["synd_ok"] == 0).sum() < F
 
 
+@pytest.mark.parametrize("rule,param", [("NMS", 0.75), ("NMS", 0.7), ("OMS", 0.35), ("MS", 0.0)])
+@pytest.mark.parametrize("synd", [False, True])
+def test_fp16_packed_check_node_kernel_is_bit_identical(q, O, torch, gold, rule, param, synd):
+    """Default fp16 configuration (two frames per lane, no message freezing) runs the packed binary16 fold of
+    qldpc_kernels_h16.h; it must give what the fp32-widening kernel gives, i.e. the rounding oracle -- posteriors included when
+    every frame runs all iterations.  Irregular code, so several degree buckets (and the generic kernel for dc > 40) mix."""
+    code = q.Code.ira(4096, 3400, 0.3, 9, 3, 5)
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    F = 300
+    llr = bsc_frames(np.random.default_rng(77), F, code.N, 0.018, 4.0)
+    ref = O.decode(og, llr, rule, param, 14, "flooding", synd, 1, n_threads=8, msg_fp16=True)
+    dec = q.Decoder(code, code.N, 14, rule=rule, rule_param=param, n_frames=F, enable_syndrome=synd, msg_dtype="f16")
+    hard, it, ok, post = staged(q, torch, dec, llr, want_post=not synd)
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+    if not synd:
+        assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("V", [1, 2, 4])
 @pytest.mark.parametrize("rule,param", [("NMS", 0.75), ("OMS", 0.35), ("MS", 0.0)])
 def test_fp16_message_storage_is_bit_exact_against_the_rounding_oracle(q, O, torch, peg, rule, param, V):

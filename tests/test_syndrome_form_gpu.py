@@ -78,3 +78,21 @@ def test_syndrome_of_and_reload_clears_the_target(q, O, torch, gold):
     dec.run()
     ok2 = dec.fetch_status()[1].cpu().numpy()
     assert ok1.mean() > 0.9 and ok2.mean() < 0.1
+
+
+@pytest.mark.parametrize("V", [1, 2])
+def test_syndrome_form_with_binary16_messages(q, O, torch, gold, V):
+    """V = 2 takes the packed check-node kernel (qldpc_kernels_h16.h), V = 1 the generic one: both must equal the rounding oracle."""
+    rng = np.random.default_rng(40 + V)
+    F = 200
+    code, og, x, s, y, mag = setup(q, O, gold, rng, F, 0.045)
+    llr = np.where(y == 1, -mag, mag).astype(np.float32)
+    for rule, param in (("NMS", 0.75), ("OMS", 0.3), ("NMS", 0.7)):       # 0.7 is not a binary16 number: the rule must stay in fp32
+        ref = O.decode(og, llr, rule, param, 30, "flooding", True, 1, n_threads=8, target=s, msg_fp16=True)
+        dec = q.Decoder(code, 1008, 30, rule=rule, rule_param=param, n_frames=F, frames_per_lane=V, msg_dtype="f16")
+        dec.load_bits(torch.from_numpy(i32(q.pack_bits(y))).cuda(), torch.full((F,), float(mag), device="cuda"))
+        dec.load_syndrome(torch.from_numpy(i32(q.pack_bits(s))).cuda())
+        dec.run()
+        hard = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), 1008)
+        it, ok = dec.fetch_status()
+        assert (hard == ref["hard"]).all() and (it.cpu().numpy() == ref["iters"]).all() and (ok.cpu().numpy() == ref["synd_ok"]).all()
