@@ -124,3 +124,32 @@ def test_fp16_message_storage_changes_little(O, peg):
     a = O.decode(peg, llr, "NMS", 0.75, 20)
     b = O.decode(peg, llr, "NMS", 0.75, 20, msg_fp16=True)
     assert (a["synd_ok"] == b["synd_ok"]).mean() > 0.9 and np.abs(a["iters"] - b["iters"]).max() <= 3
+
+
+@pytest.mark.parametrize("sched,n_ite", [("flooding", 4), ("hlayered", 2)])
+@pytest.mark.parametrize("rule,param", [("MS", 0.0), ("OMS", 1.0), ("NMS", 1.0)])
+def test_fixed_point_decoder_equals_the_float_one_while_nothing_saturates(O, peg, rule, param, sched, n_ite):
+    """The integer restatement (orc_decode_i8, what the 8-bit GPU variant is tested against) is pinned to the float decoder
+    (itself pinned by the KAT): on integer-valued LLRs, with rules that stay in the integers (offset 1, factor 1) and few
+    enough iterations that neither the +-127 (flooding) nor the +-31 (layered) message clamp is reached, both compute the
+    same numbers exactly."""
+    rng = np.random.default_rng(5)
+    llr = np.where(rng.random((40, 1008)) < 0.06, -3.0, 3.0).astype(np.float32)
+    a = O.decode(peg, llr, rule, param, n_ite, sched, enable_syndrome=False)
+    b = O.decode(peg, llr, rule, param, n_ite, sched, enable_syndrome=False, msg_i8=True, quant_scale=1.0)
+    lim = 127 if sched == "flooding" else 31
+    assert np.abs(a["post"]).max() < lim                                 # the premise: no clamp was active
+    assert (a["post"] == b["post"]).all() and (a["hard"] == b["hard"]).all() and (a["synd_ok"] == b["synd_ok"]).all()
+
+
+def test_fixed_point_quantiser_and_rules(O, peg):
+    llr = np.zeros((1, 1008), np.float32)
+    llr[0, :8] = [0.124, 0.126, -0.374, 31.7, 31.9, -40.0, 1e9, -1e9]   # scale 4: 0.496 -> 0, 0.504 -> 1, -1.496 -> -1, 126.8 -> 127, clamp
+    r = O.decode(peg, llr, "MS", 0.0, 0, enable_syndrome=False, msg_i8=True, quant_scale=4.0)     # zero iterations: posterior = quantised LLR
+    assert r["post"][0, :8].tolist() == [0, 1, -1, 127, 127, -127, 127, -127]
+    # NMS factor is rint(alpha * 128) / 128 applied with a floor: a lone-error frame shows (m * 96) >> 7 on its first messages
+    llr = np.full((1, 1008), 2.5, np.float32)                             # -> 10
+    llr[0, 17] = -2.5
+    r = O.decode(peg, llr, "NMS", 0.75, 1, enable_syndrome=False, msg_i8=True, quant_scale=4.0)
+    m = (10 * 96) >> 7                                                    # 7
+    assert set(np.unique(r["post"][0]).tolist()) == {10 + 3 * m, 10 + m, -10 + 3 * m}   # untouched VNs, neighbours of the flipped VN's checks, the flipped VN
