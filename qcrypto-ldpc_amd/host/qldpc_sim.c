@@ -12,6 +12,7 @@
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
  *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
  *                  [-d parity_ber (dirty disclosed parity bits, BS/data_dvb/data5)]
+ *                  [-R (with -e: report every random pattern -- one per batch -- and keep the best; -o file writes its VN indices)]
  *                  [-Q 32|16|8 (message storage: fp32 = the AFF3CT float build, binary16, 8-bit fixed-point min-sum)]
  *                  [-e f (puncture parity bits to reach the rate min_cr(ber, f); random pattern re-drawn per batch, main.cpp:321-333,359-362)]
  */
@@ -50,14 +51,15 @@ static int die(const char *what, int rc)
 
 int main(int argc, char **argv)
 {
-    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, msg_bits = 32, opt;
+    int N = 8192, K = 6554, n_ite = 50, frames = 256, batch = 256, layered = 0, synd = 1, peg = 0, msg_bits = 32, search = 0, opt;
+    const char *pattern_out = NULL;
     double parity_ber = 0.0;      /* > 0: the disclosed parity bits are themselves wrong with this probability (main.cpp (test effect of dirty parities)) */
     double target_eff = 0.0;      /* > 0: puncture parity bits up to min_cr(ber, f), as BS/src/main.cpp:235-333 does */
     const char *alist = NULL, *qc = NULL, *rule_name = "NMS";
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:Q:ln")) != -1) {
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:Q:o:Rln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -74,6 +76,8 @@ int main(int argc, char **argv)
         case 'e': target_eff = atof(optarg); break;
         case 'd': parity_ber = atof(optarg); break;
         case 'Q': msg_bits = atoi(optarg); break;
+        case 'R': search = 1; break;
+        case 'o': pattern_out = optarg; break;
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -130,9 +134,11 @@ int main(int argc, char **argv)
             printf("# ber %.4f: puncturing %d of %d parity bits -> rate %.4f, efficiency f = %.3f\n", ber, n_punct, n_par, (double)K / (N - n_punct),
                    ((double)(n_par - n_punct) / K) / (double)qldpc_binary_entropy((float)ber));
         }
-        long fra = 0, be = 0, fe = 0;
+        long fra = 0, be = 0, fe = 0, best_fe = -1, best_be = -1, n_pat = 0;
+        int *best_pat = (search && n_punct > 0) ? (int *)malloc(sizeof(int) * (size_t)n_punct) : NULL;
         double t_dec = 0.0;
         while (fra < frames) {
+            long pat_be = 0, pat_fe = 0;
             const int nb = frames - fra < batch ? (int)(frames - fra) : batch;
             for (long i = 0; i < (long)nb * K; i++) ref_bits[i] = (int)(rng_next() & 1);
             if ((rc = qldpc_encode(enc, ref_bits, enc_bits, nb))) return die("encode", rc);
@@ -153,9 +159,25 @@ int main(int argc, char **argv)
             for (int f = 0; f < nb; f++) {
                 long e = 0;
                 for (int i = 0; i < K; i++) e += dec_bits[(size_t)f * K + i] != ref_bits[(size_t)f * K + i];
-                be += e; fe += e > 0;
+                be += e; fe += e > 0; pat_be += e; pat_fe += e > 0;
             }
             fra += nb;
+            if (best_pat) {      /* the reference's random search (main.cpp:321-333): one shuffled pattern per simulation round, keep the best */
+                printf("#   pattern %3ld: FE %ld / %d, BE %ld\n", n_pat, pat_fe, nb, pat_be);
+                if (best_fe < 0 || pat_fe < best_fe || (pat_fe == best_fe && pat_be < best_be)) { best_fe = pat_fe; best_be = pat_be; memcpy(best_pat, par_pos, sizeof(int) * (size_t)n_punct); }
+                n_pat++;
+            }
+        }
+        if (best_pat) {
+            printf("# ber %.4f: best of %ld patterns: FE %ld, BE %ld per %d frames\n", ber, n_pat, best_fe, best_be, batch);
+            if (pattern_out) {
+                FILE *fo = fopen(pattern_out, "w");
+                if (!fo) { perror(pattern_out); return 1; }
+                fprintf(fo, "# qldpc_sim puncture pattern: N %d K %d ber %.4f punctured %d FE %ld\n", N, K, ber, n_punct, best_fe);
+                for (int i = 0; i < n_punct; i++) fprintf(fo, "%d\n", best_pat[i]);
+                fclose(fo);
+            }
+            free(best_pat);
         }
         printf("  %8.4f | %8ld | %8ld | %8ld | %9.2e | %9.2e | %10.3f\n", ber, fra, be, fe, (double)be / ((double)fra * K), (double)fe / (double)fra,
                (double)fra * K / t_dec / 1e6);

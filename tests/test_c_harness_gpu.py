@@ -57,3 +57,24 @@ def test_puncturing_to_a_target_efficiency():
     m = re.search(r"puncturing (\d+) of (\d+) parity bits -> rate ([0-9.]+), efficiency f = ([0-9.]+)", line)
     n_p, n_par, rate, f = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
     assert 0 < n_p < n_par and 0.70 < rate < 0.81 and 1.75 < f < 1.85
+
+
+def test_puncture_pattern_search_and_message_widths(tmp_path):
+    """-R: the reference's random pattern search (one shuffled pattern per simulation round, BS/src/main.cpp:321-333) keeps
+    the best pattern and writes it out; -Q 8 / 16 run the same harness on the narrow message variants."""
+    pat = tmp_path / "best.txt"
+    out = run("-N", "16384", "-K", "11469", "-r", "NMS", "-p", "0.75", "-i", "50", "-f", "256", "-b", "64", "-s", "0.02:0.02:0.01", "-e", "1.6", "-R",
+              "-o", str(pat), "-Q", "8")
+    assert "8-bit messages" in out
+    pats = [l for l in out.splitlines() if l.startswith("#   pattern")]
+    assert len(pats) == 4                                                # 256 frames / 64 per batch
+    best = [l for l in out.splitlines() if "best of 4 patterns" in l]
+    assert len(best) == 1
+    import re
+    fes = [int(re.search(r"FE (\d+) /", l).group(1)) for l in pats]
+    assert int(re.search(r"FE (\d+),", best[0]).group(1)) == min(fes)
+    idx = [int(l) for l in pat.read_text().splitlines() if not l.startswith("#")]
+    n_p = int(re.search(r"puncturing (\d+) of", out).group(1))
+    assert len(idx) == n_p == len(set(idx)) and min(idx) >= 11469 and max(idx) < 16384      # parity VNs only
+    out16 = run("-N", "8192", "-K", "6554", "-r", "NMS", "-p", "0.75", "-f", "128", "-b", "128", "-s", "0.02:0.02:0.01", "-Q", "16")
+    assert "16-bit messages" in out16 and rows(out16)[0]["fe"] == 0
