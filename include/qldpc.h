@@ -124,6 +124,14 @@ int qldpc_code_ira(int N, int K, float hi_frac, int dv_hi, int dv_lo, uint64_t s
  * 2 (depth + 1) is closed while avoidable (depth 2: no 4-cycles).  Deterministic in (profile, depth, seed).
  */
 int qldpc_code_ira_peg(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out);
+/*
+ * Quasi-cyclic code whose base graph is grown by PEG with a circulant shift per edge chosen so that the cycles closed in
+ * the base graph stay open in the lifted graph (what the reference's ldpc_examples/psd-peg.py:281-447 does, regular
+ * information-column degree dv, parity part = identity, output also as an AFF3CT .qc file when qc_path != NULL):
+ * N = (n_cols + m_rows) Z, M = m_rows Z.  *base_girth (optional) = shortest cycle closed in the base graph (0 = none);
+ * no cycle of length 4 exists in the lifted graph.  Deterministic in (n_cols, m_rows, dv, Z, seed).
+ */
+int qldpc_code_qc_peg(int n_cols, int m_rows, int dv, int Z, uint64_t seed, const char *qc_path, qldpc_code **out, int *base_girth);
 void qldpc_code_free(qldpc_code *code);
 int qldpc_code_n(const qldpc_code *code);
 int qldpc_code_m(const qldpc_code *code);

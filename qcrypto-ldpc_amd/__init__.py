@@ -92,6 +92,7 @@ _sig("qldpc_code_ira_peg", C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_i
 _sig("qldpc_code_free", None, [_vp])
 for _n in ("n", "m", "e", "max_cn_degree", "max_vn_degree", "is_ira", "layer_count"):
     _sig("qldpc_code_" + _n, C.c_int, [_vp])
+_sig("qldpc_code_qc_peg", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_char_p, C.POINTER(_vp), _ip])
 _sig("qldpc_code_export_edges", C.c_int, [_vp, _ip, _ip])
 _sig("qldpc_code_layer_order", C.c_int, [_vp, _ip, _ip])
 _sig("qldpc_code_syndrome_host", C.c_int, [_vp, _ip, _ip])
@@ -220,6 +221,18 @@ class Code:
         h = _vp()
         _chk(_L.qldpc_code_ira_peg(int(N), int(K), float(hi_frac), int(dv_hi), int(dv_lo), int(depth), int(seed), C.byref(h)), "Code.ira_peg")
         return cls(h.value)
+
+    @classmethod
+    def qc_peg(cls, n_cols, m_rows, dv, Z, seed=1, qc_path=None):
+        """QC code, base graph by PEG with cycle-breaking circulant shifts (the reference's psd-peg.py), H = [lift(P) | I].
+        The returned code carries .base_girth; qc_path also writes the AFF3CT .qc file."""
+        h = _vp()
+        g = C.c_int(0)
+        _chk(_L.qldpc_code_qc_peg(int(n_cols), int(m_rows), int(dv), int(Z), int(seed), qc_path.encode() if qc_path else None, C.byref(h), C.byref(g)),
+             "Code.qc_peg")
+        c = cls(h.value)
+        c.base_girth = g.value
+        return c
 
     def edges(self):
         var = np.empty(self.E, np.int32)

@@ -275,6 +275,27 @@ done:
     return rc;
 }
 
+/* base matrix B[mb][nb] of circulant shifts (-1 = zero block) -> lifted code: row i*Z+z meets column j*Z + (z+s) % Z */
+static int qc_expand(int nb, int mb, int Z, const int *B, qldpc_code **out)
+{
+    long blocks = 0;
+    for (long i = 0; i < (long)nb * mb; i++) if (B[i] >= 0) blocks++;
+    const long E = blocks * Z;
+    if (E <= 0 || E > 0x7fffffff) { qldpc_set_error("qc: empty or oversized matrix"); return QLDPC_EIO; }
+    int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
+    if (!var || !chk) { free(var); free(chk); return QLDPC_ENOMEM; }
+    long e = 0;
+    for (int i = 0; i < mb; i++)
+        for (int j = 0; j < nb; j++) {
+            const int s = B[(long)i * nb + j];
+            if (s < 0) continue;
+            for (int z = 0; z < Z; z++, e++) { chk[e] = i * Z + z; var[e] = j * Z + (z + s) % Z; }
+        }
+    int rc = qldpc_code_from_edges(nb * Z, mb * Z, (int)E, var, chk, out);
+    free(var); free(chk);
+    return rc;
+}
+
 /* AFF3CT .qc: "cols rows Z", then rows x cols shifts; -1 = zero block, s = identity right-shifted by s. */
 int qldpc_code_from_qc(const char *path, qldpc_code **out)
 {
@@ -286,25 +307,12 @@ int qldpc_code_from_qc(const char *path, qldpc_code **out)
     if (fscanf(f, "%d %d %d", &nb, &mb, &Z) != 3 || nb <= 0 || mb <= 0 || Z <= 0) { fclose(f); qldpc_set_error("qc: bad header in %s", path); return QLDPC_EIO; }
     int *B = (int *)malloc(sizeof(int) * (size_t)nb * mb);
     if (!B) { fclose(f); return QLDPC_ENOMEM; }
-    long blocks = 0;
     for (long i = 0; i < (long)nb * mb; i++) {
         if (fscanf(f, "%d", &B[i]) != 1 || B[i] < -1) { free(B); fclose(f); qldpc_set_error("qc: bad entry %ld", i); return QLDPC_EIO; }
-        if (B[i] >= 0) blocks++;
     }
     fclose(f);
-    const long E = blocks * Z;
-    if (E <= 0 || E > 0x7fffffff) { free(B); qldpc_set_error("qc: empty or oversized matrix"); return QLDPC_EIO; }
-    int *var = (int *)malloc(sizeof(int) * (size_t)E), *chk = (int *)malloc(sizeof(int) * (size_t)E);
-    if (!var || !chk) { free(B); free(var); free(chk); return QLDPC_ENOMEM; }
-    long e = 0;
-    for (int i = 0; i < mb; i++)
-        for (int j = 0; j < nb; j++) {
-            const int s = B[(long)i * nb + j];
-            if (s < 0) continue;
-            for (int z = 0; z < Z; z++, e++) { chk[e] = i * Z + z; var[e] = j * Z + (z + s) % Z; }
-        }
-    int rc = qldpc_code_from_edges(nb * Z, mb * Z, (int)E, var, chk, out);
-    free(B); free(var); free(chk);
+    int rc = qc_expand(nb, mb, Z, B, out);
+    free(B);
     return rc;
 }
 
@@ -622,5 +630,132 @@ done:
     if (vcn) for (int v = 0; v < N; v++) free(vcn[v].a);
     if (bucket) for (int d = 0; d <= maxdeg_cap; d++) free(bucket[d].a);
     free(cvn); free(vcn); free(cdeg); free(stamp_c); free(stamp_v); free(lvl_c); free(fr); free(fr2); free(bucket); free(bpos); free(var); free(chk);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ QC base graph by PEG + shift design ------- */
+
+/*
+ * What the reference's ldpc_examples/psd-peg.py sets out to do (its header cites the PSD-PEG paper; the script's loop is at
+ * :281-414): grow a base graph of n_cols information columns of degree dv over m_rows rows by progressive edge growth
+ * -- first edge to the lowest-degree row, then rows not reached from the column come first, deeper ones next, ties to the
+ * lower degree (:386-389) -- and give every edge a circulant shift such that the cycle the new edge closes in the base graph
+ * does not close in the lifted graph: the alternating sum of shifts around it must not vanish mod Z (:397-402).  The
+ * parity part is the identity, as the script prints it (:444-447): H = [lift(P) | I], N = (n_cols + m_rows) Z.
+ * Differences, on purpose: the alternating sum is accumulated along the whole tree path (the script keeps the last two
+ * edges only), every 4-cycle through the new edge is tested explicitly (the tree holds one path per row), shifts are
+ * drawn from [0, Z) (the script's randint(0, L) includes L), and the generator is seeded.
+ */
+typedef struct { int *v; int n, cap; } qcp_list;
+static int qcp_push(qcp_list *l, int x)
+{
+    if (l->n == l->cap) { int nc = l->cap ? 2 * l->cap : 8; int *t = (int *)realloc(l->v, sizeof(int) * (size_t)nc); if (!t) return 0; l->v = t; l->cap = nc; }
+    l->v[l->n++] = x;
+    return 1;
+}
+static long qcp_mod(long a, long Z) { a %= Z; return a < 0 ? a + Z : a; }
+
+int qldpc_code_qc_peg(int n_cols, int m_rows, int dv, int Z, uint64_t seed, const char *qc_path, qldpc_code **out, int *base_girth)
+{
+    if (!out) return QLDPC_EINVAL;
+    *out = NULL;
+    if (n_cols <= 0 || m_rows <= 0 || Z <= 1 || dv < 1 || dv > m_rows) { qldpc_set_error("qc_peg: need n_cols, m_rows > 0, Z > 1, 1 <= dv <= m_rows"); return QLDPC_EINVAL; }
+    if ((long)(n_cols + m_rows) * Z > 0x3fffffffL) { qldpc_set_error("qc_peg: lifted size too large"); return QLDPC_ESIZE; }
+    const int nb = n_cols + m_rows;
+    int *B = (int *)malloc(sizeof(int) * (size_t)nb * m_rows);
+    qcp_list *row_cols = (qcp_list *)calloc((size_t)m_rows, sizeof(qcp_list));      /* information columns of each row */
+    qcp_list *col_rows = (qcp_list *)calloc((size_t)n_cols, sizeof(qcp_list));
+    int *level = (int *)malloc(sizeof(int) * (size_t)m_rows), *order = (int *)malloc(sizeof(int) * (size_t)m_rows);
+    long *S = (long *)malloc(sizeof(long) * (size_t)m_rows);
+    int *queue = (int *)malloc(sizeof(int) * (size_t)m_rows);
+    char *col_seen = (char *)malloc((size_t)n_cols);
+    int rc = QLDPC_OK, girth = 0;
+    if (!B || !row_cols || !col_rows || !level || !order || !S || !queue || !col_seen) { rc = QLDPC_ENOMEM; goto done; }
+    for (long i = 0; i < (long)nb * m_rows; i++) B[i] = -1;
+    xoshiro rng;
+    { uint64_t sm = seed ^ 0x51c0de5eedull; for (int i = 0; i < 4; i++) rng.s[i] = splitmix64(&sm); }
+#define QCP_B(i, j) B[(long)(i) * nb + (j)]
+    for (int j = 0; j < n_cols; j++) {
+        /* first edge: lowest-degree row (lowest index on ties), random shift */
+        int c0 = 0;
+        for (int i = 1; i < m_rows; i++) if (row_cols[i].n < row_cols[c0].n) c0 = i;
+        QCP_B(c0, j) = (int)xo_below(&rng, (uint64_t)Z);
+        if (!qcp_push(&row_cols[c0], j) || !qcp_push(&col_rows[j], c0)) { rc = QLDPC_ENOMEM; goto done; }
+        if (dv == 1) continue;
+        /* breadth-first tree from column j: level of each reached row and the alternating shift sum along its tree path */
+        for (int i = 0; i < m_rows; i++) level[i] = -1;
+        memset(col_seen, 0, (size_t)n_cols);
+        col_seen[j] = 1;
+        int qh = 0, qt = 0;
+        level[c0] = 0; S[c0] = QCP_B(c0, j); queue[qt++] = c0;
+        while (qh < qt) {
+            const int a = queue[qh++];
+            for (int x = 0; x < row_cols[a].n; x++) {
+                const int k = row_cols[a].v[x];
+                if (col_seen[k]) continue;
+                col_seen[k] = 1;
+                const long sk = S[a] - QCP_B(a, k);
+                for (int y = 0; y < col_rows[k].n; y++) {
+                    const int b = col_rows[k].v[y];
+                    if (level[b] >= 0) continue;
+                    level[b] = level[a] + 1; S[b] = sk + QCP_B(b, k); queue[qt++] = b;
+                }
+            }
+        }
+        /* rows by preference: unreached first, then deeper, then lower degree, then lower index (insertion sort, m_rows is small) */
+        for (int i = 0; i < m_rows; i++) order[i] = i;
+        for (int i = 1; i < m_rows; i++) {
+            const int r = order[i];
+            const long kr = (level[r] < 0 ? 0x40000000L : level[r]);
+            int t = i - 1;
+            while (t >= 0) {
+                const int q = order[t];
+                const long kq = (level[q] < 0 ? 0x40000000L : level[q]);
+                const int before = kr > kq || (kr == kq && (row_cols[r].n < row_cols[q].n || (row_cols[r].n == row_cols[q].n && r < q)));
+                if (!before) break;
+                order[t + 1] = q; t--;
+            }
+            order[t + 1] = r;
+        }
+        int taken = 0;
+        for (int oi = 0; oi < m_rows && taken < dv - 1; oi++) {
+            const int c = order[oi];
+            if (QCP_B(c, j) >= 0) continue;
+            if (level[c] >= 0) { const int cyc = 2 * level[c] + 2; if (girth == 0 || cyc < girth) girth = cyc; }
+            int perm = 0, ok = 0;
+            for (int attempt = 0; attempt < 4096 && !ok; attempt++) {
+                perm = (int)xo_below(&rng, (uint64_t)Z);
+                ok = 1;
+                if (level[c] >= 0 && qcp_mod(S[c] - perm, Z) == 0) ok = 0;             /* the tree path's cycle would close in the lifted graph */
+                for (int y = 0; ok && y < col_rows[j].n; y++) {                          /* every 4-cycle j - a - k - c - j */
+                    const int a = col_rows[j].v[y];
+                    for (int x = 0; ok && x < row_cols[a].n; x++) {
+                        const int k = row_cols[a].v[x];
+                        if (k == j || QCP_B(c, k) < 0) continue;
+                        if (qcp_mod((long)QCP_B(a, j) - QCP_B(a, k) + QCP_B(c, k) - perm, Z) == 0) ok = 0;
+                    }
+                }
+            }
+            if (!ok) { qldpc_set_error("qc_peg: no admissible shift for block (%d, %d) with Z = %d", c, j, Z); rc = QLDPC_EUNSUPPORTED; goto done; }
+            QCP_B(c, j) = perm;
+            if (!qcp_push(&row_cols[c], j) || !qcp_push(&col_rows[j], c)) { rc = QLDPC_ENOMEM; goto done; }
+            taken++;
+        }
+    }
+    for (int i = 0; i < m_rows; i++) QCP_B(i, n_cols + i) = 0;                           /* H2 = I */
+#undef QCP_B
+    if (qc_path) {
+        FILE *f = fopen(qc_path, "w");
+        if (!f) { qldpc_set_error("qc_peg: cannot write %s", qc_path); rc = QLDPC_EIO; goto done; }
+        fprintf(f, "%d %d %d\n\n", nb, m_rows, Z);
+        for (int i = 0; i < m_rows; i++) { for (int c = 0; c < nb; c++) fprintf(f, "%d ", B[(long)i * nb + c]); fprintf(f, "\n"); }
+        fclose(f);
+    }
+    rc = qc_expand(nb, m_rows, Z, B, out);
+    if (base_girth) *base_girth = girth;      /* shortest cycle an edge closed in the BASE graph (0: none closed) */
+done:
+    if (row_cols) for (int i = 0; i < m_rows; i++) free(row_cols[i].v);
+    if (col_rows) for (int i = 0; i < n_cols; i++) free(col_rows[i].v);
+    free(row_cols); free(col_rows); free(B); free(level); free(order); free(S); free(queue); free(col_seen);
     return rc;
 }

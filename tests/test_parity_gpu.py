@@ -392,3 +392,25 @@ def test_fp16_message_storage_full_size_fer_and_requests(q, O, torch):
         with pytest.raises(q.QldpcError) as e:
             q.Decoder(code, enc.K, 5, rule="NMS", n_frames=4, msg_dtype="f16", **kw)
         assert e.value.status == -7
+
+
+def test_generated_qc_peg_code_decodes_bit_exact(q, O, torch):
+    """a code from qldpc_code_qc_peg (the reference's psd-peg.py as a C generator): weight-1 parity columns, regular dv = 3
+    information part; flooding and layered NMS against the oracle, and the frames are actually corrected."""
+    code = q.Code.qc_peg(12, 6, 3, 211, seed=5)
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    F = 192
+    llr = bsc_frames(np.random.default_rng(12), F, code.N, 0.02, 3.9)
+    llr[:, 12 * 211:] = 23.02585                                 # disclosed parity of the all-zero word
+    for sched in ("flooding", "hlayered"):
+        g2 = og
+        if sched == "hlayered":
+            order, _, _ = code.layer_order()
+            inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+            g2 = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+        ref = O.decode(g2, llr, "NMS", 0.75, 30, sched, n_threads=8)
+        dec = q.Decoder(code, code.N, 30, rule="NMS", rule_param=0.75, n_frames=F, schedule=sched)
+        hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
+        assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+        assert ok.mean() > 0.9 and (hard[ok == 1] == 0).all()
