@@ -50,6 +50,18 @@ int main(int argc, char **argv)
     CHECK(qldpc_code_ira(1000, 900, 0.4f, 14, 4, 3, &c) == QLDPC_OK);     /* high rate, many repairs */
     qldpc_code_free(c);
     CHECK(qldpc_code_ira(100, 99, 0.1f, 3, 3, 1, &c) == QLDPC_EINVAL);
+    {
+        int girth = -1;
+        CHECK(qldpc_code_qc_peg(12, 6, 3, 601, 3, NULL, &c, &girth) == QLDPC_OK && qldpc_code_n(c) == 18 * 601 && (girth == 4 || girth == 6));
+        qldpc_code_free(c);
+        CHECK(qldpc_code_qc_peg(40, 8, 4, 53, 1, "/tmp/qldpc_sanitize.qc", &c, NULL) == QLDPC_OK);
+        qldpc_code_free(c);
+        CHECK(qldpc_code_from_qc("/tmp/qldpc_sanitize.qc", &c) == QLDPC_OK && qldpc_code_m(c) == 8 * 53);
+        qldpc_code_free(c);
+        remove("/tmp/qldpc_sanitize.qc");
+        CHECK(qldpc_code_qc_peg(4, 2, 2, 2, 1, NULL, &c, NULL) != QLDPC_OK && c == NULL);      /* Z = 2: no admissible shifts */
+        CHECK(qldpc_code_qc_peg(12, 6, 7, 601, 3, NULL, &c, NULL) == QLDPC_EINVAL);
+    }
     CHECK(qldpc_parity_bits_to_punct(64800, 48600, 0.8f) == 4050);
     printf("graph layer: sanitizer pass ok\n");
     return 0;
