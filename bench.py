@@ -85,7 +85,15 @@ def cpu_baseline(code, frames_llr_fn, rule, param, n_ite, K):
     r = O.decode(og, llr, rule, param, n_ite, "flooding", False, 1, n_threads=cores)
     dt = time.time() - t0
     ok = int((r["synd_ok"] == 1).sum())
-    return dict(value=ok * K / dt / 1e6, unit="Mbit/s", cores=cores, kind="port",
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return dict(value=ok * K / dt / 1e6, unit="Mbit/s", cores=cores, cpu_model=model, kind="port",
                 sample="%d frames of the same workload (flooding %s %.2f, %d iterations fixed), %.1f s wall" % (n, rule, param, n_ite, dt)), r, llr
 
 
@@ -316,6 +324,7 @@ def main():
             "dtype": {"f32": "f32", "f16": "f32 (binary16 message storage)", "i8": "int8"}[args.msg_dtype],
             "data": "synthetic",
             "fer": fer,
+            "sifted_key_Mbit_s": value * N / K,        # the same frames counted with all N VNs
             "iterations_executed": fixed_iters,
             "frames_per_step": int(n_all),
             "config": {
