@@ -248,7 +248,7 @@ def main():
         torch.cuda.empty_cache()
 
     # ---- variants (NOT the headline): narrower message storage -------------------------------------------------
-    # f16: messages rounded to binary16 in HBM, fp32 arithmetic.  i8: 8-bit fixed-point min-sum (quantiser 4 steps per LLR
+    # f16: messages rounded to binary16 in HBM, fp32 arithmetic.  i8: 8-bit fixed-point min-sum (quantiser 8 steps per LLR
     # unit, messages saturating at +-127).  Both are FER-tolerance class against the AFF3CT float build and bit-exact
     # against the oracle run with the same arithmetic (tests/test_parity_gpu.py, tests/test_i8_gpu.py).
     def variant(msg_dtype):

@@ -170,7 +170,7 @@ typedef struct qldpc_decoder_cfg {
                             kept in 8 bits as well; FRAMES engine, 4 frames per lane):
                             a quarter of the bytes per iteration, FER-tolerance class against AFF3CT, bit-exact against the
                             oracle's integer decoder; qldpc_fetch_post_dev then returns the integer posteriors           */
-    float quant_scale;   /* msg_dtype 2: quantiser steps per LLR unit (0 = 4.0); OMS offset = rint(rule_param * quant_scale)
+    float quant_scale;   /* msg_dtype 2: quantiser steps per LLR unit (0 = 8.0); OMS offset = rint(rule_param * quant_scale)
                             steps, NMS factor = rint(rule_param * 128) / 128                                          */
     int reserved[3];     /* must be zero                                                         */
 } qldpc_decoder_cfg;

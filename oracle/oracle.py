@@ -129,7 +129,7 @@ class Graph:
 
 
 def decode(graph, llr, rule="SPA", param=0.0, n_ite=10, schedule="flooding", enable_syndrome=True,
-           syndrome_depth=1, n_threads=1, msg_fp16=False, target=None, msg_i8=False, quant_scale=4.0):
+           syndrome_depth=1, n_threads=1, msg_fp16=False, target=None, msg_i8=False, quant_scale=8.0):
     """decode_siho on llr[n_frames, N]; returns dict(post, hard, iters, synd_ok).
     msg_i8: the 8-bit fixed-point flooding min-sum (orc_decode_i8); post then holds the integer posteriors."""
     llr = np.ascontiguousarray(llr, dtype=np.float32)

@@ -227,7 +227,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         d->packed_h16 = 1;
         if (const char *e = getenv("QLDPC_PACKED_H16")) d->packed_h16 = atoi(e) ? 1 : 0;
         d->msg_i8 = cfg->msg_dtype == 2;
-        d->quant_scale = cfg->quant_scale > 0.0f ? cfg->quant_scale : 4.0f;
+        d->quant_scale = cfg->quant_scale > 0.0f ? cfg->quant_scale : 8.0f;      /* measured on the config-2 code: FER at QBER 3.0 % 0.097 (fp32) / 0.119 (scale 8) / 0.168 (scale 4) */
         if (d->msg_i8) {
             if (cfg->rule > QLDPC_RULE_NMS || cfg->engine == QLDPC_ENGINE_EDGES || cfg->freeze_messages ||
                 (cfg->frames_per_lane != 0 && cfg->frames_per_lane != QI_V)) {

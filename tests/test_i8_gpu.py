@@ -78,7 +78,7 @@ def test_irregular_code_all_degree_buckets(q, O, torch):
     og = O.Graph.from_edges(code.N, code.M, var, chk)
     llr = bsc_frames(np.random.default_rng(8), 300, code.N, 0.004, 5.5)
     for synd in (False, True):
-        ref = O.decode(og, llr, "NMS", 0.75, 10, enable_syndrome=synd, n_threads=8, msg_i8=True, quant_scale=4.0)
+        ref = O.decode(og, llr, "NMS", 0.75, 10, enable_syndrome=synd, n_threads=8, msg_i8=True, quant_scale=8.0)      # 8 = the default
         dec = q.Decoder(code, code.N, 10, rule="NMS", rule_param=0.75, n_frames=300, enable_syndrome=synd, msg_dtype="i8")
         hard, it, ok, post = run(q, torch, dec, llr, not synd)
         assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
@@ -112,7 +112,7 @@ def test_syndrome_form_and_packed_bits(q, O, torch, gold):
     y = x ^ (rng.random((F, 1008)) < qber)
     mag = np.float32(q.bsc_llr(qber))
     llr = np.where(y == 1, -mag, mag).astype(np.float32)
-    ref = O.decode(og, llr, "NMS", 0.75, 30, n_threads=8, target=s, msg_i8=True, quant_scale=4.0)
+    ref = O.decode(og, llr, "NMS", 0.75, 30, n_threads=8, target=s, msg_i8=True, quant_scale=8.0)
     dec = q.Decoder(code, 1008, 30, rule="NMS", rule_param=0.75, n_frames=F, msg_dtype="i8")
     dec.load_bits(torch.from_numpy(i32(q.pack_bits(y))).cuda(), torch.full((F,), float(mag), device="cuda"))
     dec.load_syndrome(torch.from_numpy(i32(q.pack_bits(s))).cuda())
@@ -141,7 +141,7 @@ def test_config2_code_sample_and_fer_class(q, O, torch):
     llr[:, enc.K:] = np.where(cw[:, enc.K:] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
     var, chk = code.edges()
     og = O.Graph.from_edges(code.N, code.M, var, chk)
-    ref = O.decode(og, llr, "NMS", 0.75, 50, n_threads=8, msg_i8=True, quant_scale=4.0)
+    ref = O.decode(og, llr, "NMS", 0.75, 50, n_threads=8, msg_i8=True, quant_scale=8.0)
     dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, n_frames=F, msg_dtype="i8")
     hard, it, ok, _ = run(q, torch, dec, llr, False)
     assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
@@ -179,7 +179,7 @@ def test_layered_fixed_point_bit_exact(q, O, torch, gold, rule, param, synd):
     og2, _ = _layer_graph(O, code, og)
     F = 700
     llr = bsc_frames(np.random.default_rng(21), F, 1008, 0.07, 2.6)
-    ref = O.decode(og2, llr, rule, param, 20, "hlayered", enable_syndrome=synd, n_threads=8, msg_i8=True, quant_scale=4.0)
+    ref = O.decode(og2, llr, rule, param, 20, "hlayered", enable_syndrome=synd, n_threads=8, msg_i8=True, quant_scale=8.0)
     dec = q.Decoder(code, 1008, 20, rule=rule, rule_param=param, n_frames=F, schedule="hlayered", enable_syndrome=synd, msg_dtype="i8")
     hard, it, ok, post = run(q, torch, dec, llr, not synd)
     assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
@@ -199,7 +199,7 @@ def test_layered_fixed_point_irregular_and_syndrome_form(q, O, torch):
     y = x ^ (rng.random((F, code.N)) < 0.004)
     mag = np.float32(q.bsc_llr(0.004))
     llr = np.where(y == 1, -mag, mag).astype(np.float32)
-    ref = O.decode(og2, llr, "NMS", 0.75, 12, "hlayered", n_threads=8, target=s[:, order], msg_i8=True, quant_scale=4.0)
+    ref = O.decode(og2, llr, "NMS", 0.75, 12, "hlayered", n_threads=8, target=s[:, order], msg_i8=True, quant_scale=8.0)
     dec = q.Decoder(code, code.N, 12, rule="NMS", rule_param=0.75, n_frames=F, schedule="hlayered", msg_dtype="i8")
     dec.load_bits(torch.from_numpy(i32(q.pack_bits(y))).cuda(), torch.full((F,), float(mag), device="cuda"))
     dec.load_syndrome(torch.from_numpy(i32(q.pack_bits(s))).cuda())
