@@ -200,6 +200,10 @@ int qldpc_load_llr_dev(qldpc_decoder *dec, const float *d_llr, int n_frames);
  */
 int qldpc_load_bits_dev(qldpc_decoder *dec, const uint32_t *d_bits, const float *d_llr_mag,
                         const uint8_t *d_vn_class, int n_frames);
+/* The same with a per-frame count of channel VNs: class-0 VNs at index >= d_n_channel[f] are known (shortened) bits of
+ * frame f and are pinned like class 1.  Lets blocks of different length share one code and one launch. */
+int qldpc_load_bits_short_dev(qldpc_decoder *dec, const uint32_t *d_bits, const float *d_llr_mag,
+                              const uint8_t *d_vn_class, const int *d_n_channel, int n_frames);
 /*
  * Syndrome form: instead of pinning disclosed parity VNs, every check c must come out with the
  * parity s_c that Alice computed on her key (s = H x_A).  d_synd_bits[n_frames][ceil(M/32)], MSB-first.  Call after
@@ -306,6 +310,11 @@ int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float 
 int qldpc_recon_decode_batch(qldpc_recon *r, int n_blocks, uint32_t *key_words, int key_bits, const float *qber,
                              const qldpc_recon_msg *msgs, const uint32_t *parity_words, int *status,
                              int *corrected_bits, int *iterations);
+/* Blocks of any mix of lengths and plans, one pointer per block (keys are decoded in place): grouped by plan and decoded in
+ * launches of up to max_blocks frames; within a plan the blocks may differ in length.  status[i] = QLDPC_OK | QLDPC_EDECODE. */
+int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const *key_words, const int *key_bits, const float *qber,
+                              const qldpc_recon_msg *msgs, const uint32_t *const *parity_words, int *status, int *corrected,
+                              int *iterations);
 uint32_t qldpc_crc32_words(const uint32_t *words, int n_bits);
 
 /* ------------------------------------------------------------------ privacy amplification ---- */

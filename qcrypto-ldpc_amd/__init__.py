@@ -500,6 +500,7 @@ _sig("qldpc_recon_plan", C.c_int, [_vp, C.c_int, C.c_float, C.POINTER(ReconMsg)]
 _sig("qldpc_recon_encode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, C.c_int])
 _sig("qldpc_recon_decode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
 _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
+_sig("qldpc_recon_decode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip, _ip, _ip])
 _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
 
 
@@ -575,6 +576,21 @@ class Recon:
                                          par.ctypes.data_as(_up), st.ctypes.data_as(_ip), co.ctypes.data_as(_ip),
                                          it.ctypes.data_as(_ip)), "Recon.decode_batch")
         return st, kw, co, it
+
+    def decode_blocks(self, keys, key_bits, qber, msgs, parities):
+        """blocks of any mix of lengths / plans: lists of per-block uint32 arrays; returns (status[], corrected keys, corrected[], iterations[])"""
+        n = len(keys)
+        kws = [np.array(k, dtype=np.uint32, copy=True) for k in keys]
+        pars = [np.ascontiguousarray(p, dtype=np.uint32) for p in parities]
+        kp = (_up * n)(*[k.ctypes.data_as(_up) for k in kws])
+        pp = (_up * n)(*[p.ctypes.data_as(_up) for p in pars])
+        kb = np.ascontiguousarray(key_bits, dtype=np.int32)
+        qb = np.ascontiguousarray(qber, dtype=np.float32)
+        arr = (ReconMsg * n)(*msgs)
+        st, co, it = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+        _chk(_L.qldpc_recon_decode_blocks(self._h, n, kp, kb.ctypes.data_as(_ip), qb.ctypes.data_as(_fp), arr, pp, st.ctypes.data_as(_ip),
+                                          co.ctypes.data_as(_ip), it.ctypes.data_as(_ip)), "Recon.decode_blocks")
+        return st, kws, co, it
 
     def __del__(self):
         try:

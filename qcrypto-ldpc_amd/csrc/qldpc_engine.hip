@@ -888,6 +888,13 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
 
 extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, const float *d_llr_mag, const uint8_t *d_vn_class, int n_frames)
 {
+    return qldpc_load_bits_short_dev(d, d_bits, d_llr_mag, d_vn_class, nullptr, n_frames);
+}
+
+/* as qldpc_load_bits_dev, with a per-frame count of channel VNs: class-0 VNs at index >= d_n_channel[f] are known bits of
+ * frame f (shortening: blocks of different length sharing one code), i.e. pinned like class 1 */
+extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bits, const float *d_llr_mag, const uint8_t *d_vn_class, const int *d_n_channel, int n_frames)
+{
     if (!d || !d_bits || !d_llr_mag) return QLDPC_EINVAL;
     int rc = check_frames(d, n_frames, "qldpc_load_bits_dev");
     if (rc) return rc;
@@ -898,7 +905,7 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
         hipLaunchKernelGGL(qe_load_bits, dim3((unsigned)std::min((d->N + 255) / 256, 256), (unsigned)n_frames), dim3(256), 0, d->stream, d_bits, d_llr_mag, d_vn_class,
-                           d->d_llr, d->N, W);
+                           d->d_llr, d->N, W, d_n_channel);
         LAUNCHCHK();
         d->loaded = 1; d->ran = 0;
         return QLDPC_OK;
@@ -907,9 +914,9 @@ extern "C" int qldpc_load_bits_dev(qldpc_decoder *d, const uint32_t *d_bits, con
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
         dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
         switch (d->V) {
-        case 1: hipLaunchKernelGGL((qk_load_bits<1>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
-        case 2: hipLaunchKernelGGL((qk_load_bits<2>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
-        default: hipLaunchKernelGGL((qk_load_bits<4>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames); break;
+        case 1: hipLaunchKernelGGL((qk_load_bits<1>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames, d_n_channel); break;
+        case 2: hipLaunchKernelGGL((qk_load_bits<2>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames, d_n_channel); break;
+        default: hipLaunchKernelGGL((qk_load_bits<4>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr, d->N, W, n_frames, d_n_channel); break;
         }
         LAUNCHCHK();
         if (d->msg_i8) {

@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void qk_unload_f32(const float *__restrict__ s
 template <int V>
 __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag,
                                                            const uint8_t *__restrict__ vn_class, float *__restrict__ dst,
-                                                           int N, int W, int n_frames)
+                                                           int N, int W, int n_frames, const int *__restrict__ n_channel)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -780,11 +780,13 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float mag[V];
     bool live[V];
+    int nch[V];                  /* per frame: channel VNs at v >= nch are known (shortened) bits, i.e. pinned */
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const int f = g * FG + lane * V + j;
         live[j] = f < n_frames;
         mag[j] = live[j] ? llr_mag[f] : 1.0f;
+        nch[j] = (n_channel && live[j]) ? n_channel[f] : N;
     }
     for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
         uint32_t word[V];
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 const bool y = (word[j] >> (31 - b)) & 1u;
-                const float m = (cls == 0) ? mag[j] : (cls == 1 ? 23.025850929840455f : 0.0f);
+                const float m = (cls == 0) ? (v < nch[j] ? mag[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
                 o[j] = live[j] ? (y ? -m : m) : 1.0f;
             }
             qk_store<V>(dst + ((size_t)g * N + v) * FG + lane * V, o);

@@ -207,13 +207,15 @@ __global__ void qe_init(int *__restrict__ unsat, int unsat_stride, int *__restri
 
 /* QKD frame formation for frame-major floats: bits[F][W] + |LLR| per frame + class per VN -> llr[F][N] */
 __global__ void qe_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag, const uint8_t *__restrict__ vn_class,
-                             float *__restrict__ llr, int N, int W)
+                             float *__restrict__ llr, int N, int W, const int *__restrict__ n_channel)
 {
     const int f = blockIdx.y;
     const float mag = llr_mag[f];
+    const int nch = n_channel ? n_channel[f] : N;      /* channel VNs at v >= nch are known (shortened) bits of this frame */
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
         const bool y = (bits[(size_t)f * W + (v >> 5)] >> (31 - (v & 31))) & 1u;
-        const int cls = vn_class ? vn_class[v] : 0;
+        int cls = vn_class ? vn_class[v] : 0;
+        if (cls == 0 && v >= nch) cls = 1;
         const float m = (cls == 0) ? mag : (cls == 1 ? 23.025850929840455f : 0.0f);
         llr[(size_t)f * N + v] = y ? -m : m;
     }

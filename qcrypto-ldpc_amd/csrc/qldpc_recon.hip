@@ -10,6 +10,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +40,8 @@ struct recon_entry {
     uint32_t *d_out;      /* [max_blocks][Wn] */
     float *d_mag;         /* [max_blocks] */
     int *d_iters, *d_ok;  /* [max_blocks] */
-    int cls_key_bits;     /* key_bits the class mask was built for */
+    int *d_nch;           /* [max_blocks] channel VNs per frame (block length) */
+    int cls_key_bits;     /* K once the class mask is built */
 };
 
 struct qldpc_recon {
@@ -97,7 +99,7 @@ static void entry_free(recon_entry &e)
     qldpc_decoder_free(e.dec);
     qldpc_encoder_free(e.enc);
     qldpc_code_free(e.code);
-    (void)hipFree(e.d_cls); (void)hipFree(e.d_bits); (void)hipFree(e.d_out); (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok);
+    (void)hipFree(e.d_cls); (void)hipFree(e.d_bits); (void)hipFree(e.d_out); (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok); (void)hipFree(e.d_nch);
 }
 
 extern "C" void qldpc_recon_free(qldpc_recon *r)
@@ -176,6 +178,7 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     if (!rc && hipMalloc((void **)&e.d_mag, sizeof(float) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
     if (!rc && hipMalloc((void **)&e.d_iters, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
     if (!rc && hipMalloc((void **)&e.d_ok, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
+    if (!rc && hipMalloc((void **)&e.d_nch, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
     if (rc) { entry_free(e); return rc; }
     while (r->cache.size() >= 6) { entry_free(r->cache.back()); r->cache.pop_back(); }
     r->cache.push_front(e);
@@ -219,40 +222,36 @@ extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int
     return QLDPC_OK;
 }
 
-extern "C" int qldpc_recon_decode_batch(qldpc_recon *r, int n, uint32_t *key_words, int key_bits, const float *qber, const qldpc_recon_msg *msgs,
-                                        const uint32_t *parity_words, int *status, int *corrected, int *iterations)
+/* blocks of ONE plan (same K, M), possibly of different length: one launch.  key[i] is decoded in place. */
+static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *key_bits, const float *qber, const qldpc_recon_msg *const *msgs,
+                        const uint32_t *const *parity, int *const *status, int *const *corrected, int *const *iterations)
 {
-    if (!r || !key_words || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
-    if (n > r->cfg.max_blocks) { qldpc_set_error("recon_decode_batch: %d blocks > max_blocks %d", n, r->cfg.max_blocks); return QLDPC_ESIZE; }
+    const int K = (int)msgs[0]->code_k, M = (int)msgs[0]->code_m, N = K + M;
+    const int Wk = K / 32, Wn = (N + 31) / 32;
     int rc;
-    for (int i = 0; i < n; i++) {
-        if ((rc = check_msg(r, &msgs[i], key_bits))) return rc;
-        if (msgs[i].code_k != msgs[0].code_k || msgs[i].code_m != msgs[0].code_m) { qldpc_set_error("recon_decode_batch: block %d has a different plan", i); return QLDPC_ESIZE; }
-        if (!(qber[i] > 0.0f && qber[i] < 0.5f)) { qldpc_set_error("recon_decode_batch: qber[%d]=%g", i, (double)qber[i]); return QLDPC_EINVAL; }
-    }
-    const int K = (int)msgs[0].code_k, M = (int)msgs[0].code_m, N = K + M;
-    const int Wk = K / 32, Wkey = (key_bits + 31) / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
     HIPCHK(hipSetDevice(r->cfg.device));
     recon_entry *e;
     if ((rc = get_entry(r, K, M, &e))) return rc;
-    if (e->cls_key_bits != key_bits) {
-        std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* shortened + parity VNs are known */
-        for (int i = 0; i < key_bits; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
+    if (e->cls_key_bits != K) {
+        std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* parity VNs are known; key VNs past a block's length are pinned per frame */
+        for (int i = 0; i < K; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
         HIPCHK(hipMemcpy(e->d_cls, cls.data(), (size_t)N, hipMemcpyHostToDevice));
-        e->cls_key_bits = key_bits;
+        e->cls_key_bits = K;
     }
     std::vector<uint32_t> frame((size_t)n * Wn, 0u), outw((size_t)n * Wn);
     std::vector<float> mag((size_t)n);
     for (int i = 0; i < n; i++) {
+        const int Wkey = (key_bits[i] + 31) / 32;
         uint32_t *f = frame.data() + (size_t)i * Wn;
-        memcpy(f, key_words + (size_t)i * Wkey, sizeof(uint32_t) * (size_t)Wkey);
-        if (key_bits & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (key_bits & 31));
-        memcpy(f + Wk, parity_words + (size_t)i * Wm, sizeof(uint32_t) * (size_t)(Wn - Wk));
+        memcpy(f, key[i], sizeof(uint32_t) * (size_t)Wkey);
+        if (key_bits[i] & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (key_bits[i] & 31));
+        memcpy(f + Wk, parity[i], sizeof(uint32_t) * (size_t)(Wn - Wk));
         mag[(size_t)i] = qldpc_bsc_llr(qber[i]);
     }
     HIPCHK(hipMemcpy(e->d_bits, frame.data(), sizeof(uint32_t) * frame.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_mag, mag.data(), sizeof(float) * mag.size(), hipMemcpyHostToDevice));
-    if ((rc = qldpc_load_bits_dev(e->dec, e->d_bits, e->d_mag, e->d_cls, n))) return rc;
+    HIPCHK(hipMemcpy(e->d_nch, key_bits, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    if ((rc = qldpc_load_bits_short_dev(e->dec, e->d_bits, e->d_mag, e->d_cls, e->d_nch, n))) return rc;
     if ((rc = qldpc_run(e->dec))) return rc;
     if ((rc = qldpc_fetch_packed_dev(e->dec, e->d_out))) return rc;
     if ((rc = qldpc_fetch_status_dev(e->dec, e->d_iters, e->d_ok))) return rc;
@@ -262,25 +261,83 @@ extern "C" int qldpc_recon_decode_batch(qldpc_recon *r, int n, uint32_t *key_wor
     HIPCHK(hipMemcpy(it.data(), e->d_iters, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ok.data(), e->d_ok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
+        const int kb = key_bits[i], Wkey = (kb + 31) / 32;
         const uint32_t *o = outw.data() + (size_t)i * Wn;
-        uint32_t *kw = key_words + (size_t)i * Wkey;
-        const bool good = ok[(size_t)i] && qldpc_crc32_words(o, key_bits) == msgs[i].crc32;
-        status[i] = good ? QLDPC_OK : QLDPC_EDECODE;
-        if (iterations) iterations[i] = it[(size_t)i];
+        uint32_t *kw = key[i];
+        const bool good = ok[(size_t)i] && qldpc_crc32_words(o, kb) == msgs[i]->crc32;
+        *status[i] = good ? QLDPC_OK : QLDPC_EDECODE;
+        if (iterations[i]) *iterations[i] = it[(size_t)i];
         int flips = 0;
         if (good) {
             for (int w = 0; w < Wkey; w++) {
                 uint32_t nw = o[w];
-                if (w == Wkey - 1 && (key_bits & 31)) nw &= 0xFFFFFFFFu << (32 - (key_bits & 31));
+                if (w == Wkey - 1 && (kb & 31)) nw &= 0xFFFFFFFFu << (32 - (kb & 31));
                 uint32_t old = kw[w];
-                if (w == Wkey - 1 && (key_bits & 31)) old &= 0xFFFFFFFFu << (32 - (key_bits & 31));
+                if (w == Wkey - 1 && (kb & 31)) old &= 0xFFFFFFFFu << (32 - (kb & 31));
                 flips += __builtin_popcount(old ^ nw);
                 kw[w] = nw;
             }
         }
-        if (corrected) corrected[i] = flips;
+        if (corrected[i]) *corrected[i] = flips;
     }
     return QLDPC_OK;
+}
+
+/*
+ * Blocks of any mix of lengths and plans in one call ("let many blocks queue and decode in one
+ * launch"): blocks are grouped by plan (code_k, code_m) and every group goes through the decoder in launches of up to
+ * max_blocks frames; within a group the blocks may differ in length (their unused key VNs are pinned per frame).
+ */
+extern "C" int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const *key_words, const int *key_bits, const float *qber,
+                                         const qldpc_recon_msg *msgs, const uint32_t *const *parity_words, int *status, int *corrected, int *iterations)
+{
+    if (!r || !key_words || !key_bits || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
+    int rc;
+    for (int i = 0; i < n; i++) {
+        if (!key_words[i] || !parity_words[i]) return QLDPC_EINVAL;
+        if ((rc = check_msg(r, &msgs[i], key_bits[i]))) return rc;
+        if (!(qber[i] > 0.0f && qber[i] < 0.5f)) { qldpc_set_error("recon_decode_blocks: qber[%d]=%g", i, (double)qber[i]); return QLDPC_EINVAL; }
+        status[i] = QLDPC_EDECODE;
+    }
+    std::vector<char> taken((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        if (taken[(size_t)i]) continue;
+        std::vector<int> idx;
+        for (int j = i; j < n; j++)
+            if (!taken[(size_t)j] && msgs[j].code_k == msgs[i].code_k && msgs[j].code_m == msgs[i].code_m) { idx.push_back(j); taken[(size_t)j] = 1; }
+        for (size_t at = 0; at < idx.size(); at += (size_t)r->cfg.max_blocks) {
+            const int m = (int)std::min(idx.size() - at, (size_t)r->cfg.max_blocks);
+            std::vector<uint32_t *> k((size_t)m);
+            std::vector<const uint32_t *> p((size_t)m);
+            std::vector<const qldpc_recon_msg *> mm((size_t)m);
+            std::vector<int> kb((size_t)m);
+            std::vector<float> qb((size_t)m);
+            std::vector<int *> st((size_t)m), co((size_t)m), itp((size_t)m);
+            for (int t = 0; t < m; t++) {
+                const int j = idx[at + (size_t)t];
+                k[(size_t)t] = key_words[j]; p[(size_t)t] = parity_words[j]; mm[(size_t)t] = &msgs[j]; kb[(size_t)t] = key_bits[j]; qb[(size_t)t] = qber[j];
+                st[(size_t)t] = &status[j]; co[(size_t)t] = corrected ? &corrected[j] : nullptr; itp[(size_t)t] = iterations ? &iterations[j] : nullptr;
+            }
+            if ((rc = decode_group(r, m, k.data(), kb.data(), qb.data(), mm.data(), p.data(), st.data(), co.data(), itp.data()))) return rc;
+        }
+    }
+    return QLDPC_OK;
+}
+
+/* n blocks of ONE plan and length, contiguous arrays (the config-3 stream driver's call) */
+extern "C" int qldpc_recon_decode_batch(qldpc_recon *r, int n, uint32_t *key_words, int key_bits, const float *qber, const qldpc_recon_msg *msgs,
+                                        const uint32_t *parity_words, int *status, int *corrected, int *iterations)
+{
+    if (!r || !key_words || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
+    if (n > r->cfg.max_blocks) { qldpc_set_error("recon_decode_batch: %d blocks > max_blocks %d", n, r->cfg.max_blocks); return QLDPC_ESIZE; }
+    for (int i = 0; i < n; i++)
+        if (msgs[i].code_k != msgs[0].code_k || msgs[i].code_m != msgs[0].code_m) { qldpc_set_error("recon_decode_batch: block %d has a different plan", i); return QLDPC_ESIZE; }
+    const int Wkey = (key_bits + 31) / 32, Wm = ((int)msgs[0].code_m + 31) / 32;
+    std::vector<uint32_t *> k((size_t)n);
+    std::vector<const uint32_t *> p((size_t)n);
+    std::vector<int> kb((size_t)n, key_bits);
+    for (int i = 0; i < n; i++) { k[(size_t)i] = key_words + (size_t)i * Wkey; p[(size_t)i] = parity_words + (size_t)i * Wm; }
+    return qldpc_recon_decode_blocks(r, n, k.data(), kb.data(), qber, msgs, p.data(), status, corrected, iterations);
 }
 
 extern "C" int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float qber, const qldpc_recon_msg *msg, const uint32_t *parity_words,

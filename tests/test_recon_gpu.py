@@ -121,3 +121,31 @@ def test_layered_sessions_reconcile_the_same_blocks(q):
         A.append(a); B.append(b); msgs.append(m); pars.append(par)
     st, fixed, co, it = r.decode_batch(np.stack(B), key_bits, np.full(12, 0.025, np.float32), msgs, np.stack(pars))
     assert (st == 0).all() and (fixed == np.stack(A)).all() and it.max() <= 12
+
+
+@pytest.mark.parametrize("max_blocks", [4, 16])
+def test_blocks_of_mixed_length_and_plan_in_one_call(q, max_blocks):
+    """qldpc_recon_decode_blocks: what a daemon that lets blocks queue would hand over -- blocks of
+    different length sharing a plan (K rounds up to 1 024, the unused key VNs are pinned per frame), blocks of other plans,
+    one block whose parity is corrupted.  Every block must come out exactly as the one-block call gives it."""
+    rng = np.random.default_rng(90 + max_blocks)
+    spec = [(14500, 0.02), (14900, 0.02), (15000, 0.021), (14337, 0.019),        # one plan: K = 15 360, rate 0.8, four lengths
+            (15000, 0.05), (14800, 0.048),                                         # rate 0.5 plan
+            (3000, 0.02), (64000, 0.01), (15100, 0.02), (14999, 0.02), (15360, 0.02)]
+    batch, single = q.Recon(max_blocks=max_blocks), q.Recon(max_blocks=1)
+    keys, bobs, msgs, pars = [], [], [], []
+    for kb, p in spec:
+        a, b, _ = block(q, rng, kb, p)
+        m, par = batch.encode(a, kb, p)
+        keys.append(a); bobs.append(b); msgs.append(m); pars.append(par)
+    pars[2] = pars[2].copy(); pars[2][::3] ^= 0x5a5a5a5a                            # this block must fail, alone
+    assert len({(m.code_k, m.code_m) for m in msgs[:4] + msgs[8:]}) == 1 and msgs[4].code_m != msgs[0].code_m
+    st, fixed, co, it = batch.decode_blocks(bobs, [s[0] for s in spec], [s[1] for s in spec], msgs, pars)
+    for i, (kb, p) in enumerate(spec):
+        ok1, f1, c1, _, it1 = single.decode(bobs[i], kb, p, msgs[i], pars[i])
+        assert (st[i] == 0) == ok1 and it[i] == it1, i
+        if ok1:
+            assert co[i] == c1 and (fixed[i] == f1).all() and (q.unpack_bits(fixed[i], kb) == q.unpack_bits(keys[i], kb)).all()
+        else:
+            assert i == 2 and (fixed[i] == bobs[i]).all()                           # untouched
+    assert (st == 0).sum() == len(spec) - 1
