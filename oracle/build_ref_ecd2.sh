@@ -5,7 +5,8 @@
 #   oracle/_ref/ecd2_cascade  pristine reference daemon (cascade_biconf): the integration oracle of SURVEY.md section 4
 #   oracle/_ref/ecd2_ldpc     the same sources with the four maintainer edits of INTEGRATION.md section 2 applied to a
 #                             scratch copy (the two `return 81` arms of subcomponents/qber_estim.c:337-340,420-423, the
-#                             algorithm choice at :301 made switchable with ECD2_LDPC=1, four appended error messages) and
+#                             algorithm choice at :301 made switchable with ECD2_LDPC=1, four appended error messages, the
+#                             ldpc_tick() call + ldpc_pending() time-out term in ecd2.c's main loop for batched ingest) and
 #                             linked with qcrypto-ldpc_amd/host/ldpc_reconcile.c + libqldpc.so
 # Nothing from /root/reference is copied into the repository; the scratch copy lives in a temp dir and is deleted.
 set -euo pipefail
@@ -54,6 +55,18 @@ s = s.replace(loop, "    if (getenv(\"ECD2_GPU_PA\")) {\n"
                     "      if (qldpc_privamp(0, pb->mainBufPtr, pb->workbits, seed, pb->finalKeyBits, finalkey)) return 85;\n"
                     "    } else {\n" + loop + "    }\n", 1)
 s = s.replace('#include "priv_amp.h"', '#include "priv_amp.h"\n#include "qldpc.h"\n#include <stdlib.h>', 1)
+open(p, "w").write(s)
+p = "ecd2.c"
+s = open(p).read()
+s = s.replace('#include "ecd2.h"', '#include "ecd2.h"\n#include "subcomponents/ldpc_reconcile.h"', 1)
+tail = ("      free2(tmpRecvdPktNode);                            /* ...and pointer entry */\n"
+        "    }\n")
+assert s.count(tail) == 1
+s = s.replace(tail, tail + "    { int ldpcErr = ldpc_tick(receivedPacketLinkedList == NULL);      /* batched ingest: decode what queued up */\n"
+                           "      if (ldpcErr) { emsg(ldpcErr); if (arguments.runtimeErrorMode == END_ON_ERR) return -ldpcErr; } }\n", 1)
+sel = "(cmdInput[0] || receivedPacketLinkedList) ? TENMILLISEC : HALFSECOND"
+assert s.count(sel) == 1
+s = s.replace(sel, "(cmdInput[0] || receivedPacketLinkedList || ldpc_pending()) ? TENMILLISEC : HALFSECOND", 1)
 open(p, "w").write(s)
 p = "ecd2.h"
 s = open(p).read()

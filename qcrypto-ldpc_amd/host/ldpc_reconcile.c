@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "subcomponents/cascade_biconf.h"
 #include "subcomponents/comms.h"
@@ -20,6 +21,7 @@
 #include "definitions/proc_state.h"
 
 static qldpc_recon *g_recon = NULL;
+static int ldpc_batchSize(void);
 
 int ldpc_init(int device)
 {
@@ -27,6 +29,7 @@ int ldpc_init(int device)
     if (g_recon) return 0;
     qldpc_recon_cfg_default(&cfg);
     cfg.device = device;
+    cfg.max_blocks = ldpc_batchSize();
     if (qldpc_recon_create(&cfg, &g_recon) != QLDPC_OK) {
         fprintf(stderr, "ldpc_init: %s\n", qldpc_last_error());
         return LDPC_ERR_ENGINE;
@@ -248,34 +251,36 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
 
 /* ---- EC follower ("Bob"): decode, verify, verdict, privacy amplification --------------------- */
 
-int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
+static int ldpc_parseParity(ProcessBlock *pb, const char *receivebuf, qldpc_recon_msg *msg)
 {
-    EcPktHdr_LdpcParity *in_head = (EcPktHdr_LdpcParity *)receivebuf;
-    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
-    EcPktHdr_LdpcVerdict *h10;
-    qldpc_recon_msg msg;
-    int corrected = 0, leaked = 0, iterations = 0, rc, errorCode;
-    unsigned int parityWords = (in_head->codeM + 31) / 32;
-
+    const EcPktHdr_LdpcParity *in_head = (const EcPktHdr_LdpcParity *)receivebuf;
+    const unsigned int parityWords = (in_head->codeM + 31) / 32;
     if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + parityWords * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
     if ((int)in_head->keyBits != pb->workbits) return LDPC_ERR_PKT_SIZE;
-    msg.rate_index = in_head->rateIndex;
-    msg.key_bits = in_head->keyBits;
-    msg.code_k = in_head->codeK;
-    msg.code_m = in_head->codeM;
-    msg.crc32 = in_head->crc32;
+    memset(msg, 0, sizeof(*msg));
+    msg->rate_index = in_head->rateIndex;
+    msg->key_bits = in_head->keyBits;
+    msg->code_k = in_head->codeK;
+    msg->code_m = in_head->codeM;
+    msg->crc32 = in_head->crc32;
+    return 0;
+}
 
-    /* the handler owns receivebuf only until it returns (ecd2.c:546-548): decode straight from it */
-    rc = qldpc_recon_decode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (const uint32_t *)&in_head[1], &corrected, &leaked, &iterations);
-    if (rc != QLDPC_OK && rc != QLDPC_EDECODE) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
+/* after the decode: verdict packet, then privacy amplification (or the fallback) */
+static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int decoded, int corrected, int iterations)
+{
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    EcPktHdr_LdpcVerdict *h10;
+    const int leaked = (int)msg->code_m + 32;            /* disclosed parity bits + the CRC */
+    int errorCode;
 
     if ((errorCode = ldpc_createHeader((char **)&h10, SUBTYPE_LDPC_VERDICT, sizeof(EcPktHdr_LdpcVerdict), pb))) return errorCode;
-    h10->decoded = (rc == QLDPC_OK);
+    h10->decoded = decoded ? 1 : 0;
     h10->correctedBits = (unsigned int)corrected;
     h10->iterations = (unsigned int)iterations;
     if ((errorCode = comms_insertSendPacket((char *)h10, h10->base.totalLengthInBytes))) return errorCode;
 
-    if (rc == QLDPC_EDECODE) {
+    if (!decoded) {
         /* no codeword found or CRC mismatch: mainBufPtr is untouched, the disclosed bits are spent */
         printf("ldpc: epoch %08x: no verified codeword after %d iterations\n", pb->startEpoch, iterations);
         pb->leakageBits += leaked;
@@ -283,7 +288,7 @@ int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
         pBlkMgmt_removeProcessBlk(pb->startEpoch);
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
-    ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m; ld->iterations = iterations;
+    ld->rateIndex = msg->rate_index; ld->codeK = msg->code_k; ld->codeM = msg->code_m; ld->iterations = iterations;
     printf("ldpc: epoch %08x: decoded %d key bits in %d iterations, %d errors corrected, %d bits leaked\n", pb->startEpoch, pb->workbits, iterations, corrected, leaked);
     fflush(stdout);
     pb->correctedErrors = corrected;
@@ -291,6 +296,99 @@ int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
     pb->processingState = PSTATE_PERFORMED_PARITY;
     /* same hand-over as cascade_biconf.c:892,939: send message 8 and do the PA locally */
     return privAmp_sendPrivAmpMsgAndPrivAmp(pb);
+}
+
+/*
+ * Batched ingest: with ECD2_LDPC_BATCH=n (n > 1) a parity packet is only queued; the
+ * main loop calls ldpc_tick() once per iteration and the queue is decoded in ONE qldpc_recon_decode_blocks call when it
+ * holds n blocks, or when the receive list has drained and the oldest entry has waited ECD2_LDPC_BATCH_WAIT_MS (default 0).
+ * The handler owns receivebuf only until it returns (ecd2.c:546-548), so the packet is copied.
+ */
+#define LDPC_BATCH_MAX 64
+static struct { unsigned int epoch; char *packet; } g_queue[LDPC_BATCH_MAX];
+static int g_queued = 0, g_batch = -1, g_wait_ms = 0;
+static struct timespec g_first;
+
+static int ldpc_batchSize(void)
+{
+    if (g_batch < 0) {
+        const char *e = getenv("ECD2_LDPC_BATCH"), *w = getenv("ECD2_LDPC_BATCH_WAIT_MS");
+        g_batch = e ? atoi(e) : 1;
+        if (g_batch < 1) g_batch = 1;
+        if (g_batch > LDPC_BATCH_MAX) g_batch = LDPC_BATCH_MAX;
+        g_wait_ms = w ? atoi(w) : 0;
+    }
+    return g_batch;
+}
+
+int ldpc_pending(void) { return g_queued; }
+
+static int ldpc_flush(void)
+{
+    uint32_t *keys[LDPC_BATCH_MAX];
+    const uint32_t *pars[LDPC_BATCH_MAX];
+    ProcessBlock *pbs[LDPC_BATCH_MAX];
+    qldpc_recon_msg msgs[LDPC_BATCH_MAX];
+    int bits[LDPC_BATCH_MAX], status[LDPC_BATCH_MAX], corrected[LDPC_BATCH_MAX], iterations[LDPC_BATCH_MAX];
+    float qber[LDPC_BATCH_MAX];
+    int n = 0, i, rc, errorCode = 0;
+
+    for (i = 0; i < g_queued; i++) {
+        ProcessBlock *pb = pBlkMgmt_getProcessBlk(g_queue[i].epoch);
+        if (!pb || ldpc_parseParity(pb, g_queue[i].packet, &msgs[n])) continue;      /* block gone or packet inconsistent: drop the entry */
+        pbs[n] = pb; keys[n] = pb->mainBufPtr; bits[n] = pb->workbits; qber[n] = pb->localError;
+        pars[n] = (const uint32_t *)(g_queue[i].packet + sizeof(EcPktHdr_LdpcParity));
+        n++;
+    }
+    if (n > 0) {
+        rc = qldpc_recon_decode_blocks(g_recon, n, keys, bits, qber, msgs, pars, status, corrected, iterations);
+        if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); errorCode = LDPC_ERR_ENGINE; }
+        else {
+            printf("ldpc: decoded a batch of %d blocks in one call\n", n);
+            for (i = 0; i < n; i++) {
+                const int e = ldpc_finishBlock(pbs[i], &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
+                if (e && !errorCode) errorCode = e;
+            }
+        }
+    }
+    for (i = 0; i < g_queued; i++) { free2(g_queue[i].packet); g_queue[i].packet = NULL; }
+    g_queued = 0;
+    return errorCode;
+}
+
+/* once per main-loop iteration (ecd2.c, after the received-packet part): receiveQueueEmpty = no packet waiting */
+int ldpc_tick(int receiveQueueEmpty)
+{
+    if (g_queued == 0) return 0;
+    if (g_queued < ldpc_batchSize()) {
+        struct timespec now;
+        if (!receiveQueueEmpty) return 0;
+        clock_gettime(CLOCK_MONOTONIC, &now);
+        if ((now.tv_sec - g_first.tv_sec) * 1000L + (now.tv_nsec - g_first.tv_nsec) / 1000000L < g_wait_ms) return 0;
+    }
+    return ldpc_flush();
+}
+
+int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
+{
+    EcPktHdr_LdpcParity *in_head = (EcPktHdr_LdpcParity *)receivebuf;
+    qldpc_recon_msg msg;
+    int corrected = 0, leaked = 0, iterations = 0, rc, errorCode;
+
+    if ((errorCode = ldpc_parseParity(pb, receivebuf, &msg))) return errorCode;
+    if (ldpc_batchSize() > 1) {
+        char *copy = malloc2(in_head->base.totalLengthInBytes);
+        if (!copy) return 43;
+        memcpy(copy, receivebuf, in_head->base.totalLengthInBytes);
+        if (g_queued == 0) clock_gettime(CLOCK_MONOTONIC, &g_first);
+        g_queue[g_queued].epoch = pb->startEpoch; g_queue[g_queued].packet = copy;
+        g_queued++;
+        return g_queued >= LDPC_BATCH_MAX ? ldpc_flush() : 0;      /* otherwise ldpc_tick() decides */
+    }
+    /* the handler owns receivebuf only until it returns (ecd2.c:546-548): decode straight from it */
+    rc = qldpc_recon_decode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (const uint32_t *)&in_head[1], &corrected, &leaked, &iterations);
+    if (rc != QLDPC_OK && rc != QLDPC_EDECODE) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
+    return ldpc_finishBlock(pb, &msg, rc == QLDPC_OK, corrected, iterations);
 }
 
 /* ---- EC initiator: verdict ---------------------------------------------------------------------- */

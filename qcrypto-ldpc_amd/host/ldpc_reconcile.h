@@ -62,6 +62,11 @@ extern const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC;
 int ldpc_init(int device);
 void ldpc_shutdown(void);
 
+/** batched ingest (ECD2_LDPC_BATCH=n): call ldpc_tick(receivedPacketLinkedList == NULL) once per main-loop iteration (ecd2.c, after
+ *  the received-packet part) and let the select() time-out be the short one while ldpc_pending() != 0 */
+int ldpc_tick(int receiveQueueEmpty);
+int ldpc_pending(void);
+
 /** hooks for qber_estim.c */
 int ldpc_prepareAsQberFollower(ProcessBlock *processBlock, ALGORITHM_DECISION chosenAlgorithm, char *ackToSend, unsigned int ackLength);
 int ldpc_prepareAsQberInitiator(ProcessBlock *processBlock, ALGORITHM_DECISION chosenAlgorithm);

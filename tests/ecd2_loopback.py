@@ -30,8 +30,10 @@ def read_stream7(path):
     return dict(tag=tag, epoch=epoch, nepochs=nepochs, nbits=nbits, words=words)
 
 
-def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180):
-    """alice_bits / bob_bits: lists of per-epoch 0/1 arrays. Returns dict with both final keys + logs."""
+def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180, blocks=None, cmd_gaps=(3.0, 0.06)):
+    """alice_bits / bob_bits: lists of per-epoch 0/1 arrays. Returns dict with both final keys + logs.
+    blocks: epochs per command (default: one command = one block of all epochs); with several commands written at once
+    several blocks are in flight, and out["finals"] maps each block's first epoch to its (alice, bob) stream-7 files."""
     d = str(workdir)
     for side in "ab":
         for sub in ("raw", "final"):
@@ -57,13 +59,25 @@ def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_e
     pb, lb = daemon("b", "b2a", "a2b")
     try:
         time.sleep(0.5)
+        blocks_ = blocks or [len(alice_bits)]
+        starts, e = [], epoch0
+        for nb in blocks_:
+            starts.append(e)
+            e += nb
         with open(os.path.join(d, "a_cmd"), "w") as f:
-            f.write("0x%08x %d\n" % (epoch0, len(alice_bits)))
+            # one line per write, spaced out: the daemon parses ONE command per wake-up of its command pipe, so lines that
+            # pile up while a handler is busy (the first block pays for GPU start-up and code construction) would be lost
+            for i, (st, nb) in enumerate(zip(starts, blocks_)):
+                f.write("0x%08x %d\n" % (st, nb))
+                f.flush()
+                if len(blocks_) > 1:
+                    time.sleep(cmd_gaps[0] if i == 0 else cmd_gaps[1])
         fa = os.path.join(d, "a", "final", "%08x" % epoch0)
         fb = os.path.join(d, "b", "final", "%08x" % epoch0)
+        finals = [(os.path.join(d, "a", "final", "%08x" % st), os.path.join(d, "b", "final", "%08x" % st)) for st in starts]
         t0 = time.time()
         while time.time() - t0 < timeout:
-            if os.path.exists(fa) and os.path.exists(fb) and os.path.getsize(fa) > 16 and os.path.getsize(fb) > 16:
+            if all(os.path.exists(x) and os.path.getsize(x) >= 16 for pair in finals for x in pair):      # 16 = a header with 0 bits
                 time.sleep(0.3)
                 break
             if pa.poll() is not None or pb.poll() is not None:
@@ -84,6 +98,8 @@ def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_e
                elapsed=time.time() - t0)
     out["a_final"] = read_stream7(fa) if os.path.exists(fa) else None
     out["b_final"] = read_stream7(fb) if os.path.exists(fb) else None
+    out["finals"] = {st: (read_stream7(x) if os.path.exists(x) else None, read_stream7(y) if os.path.exists(y) else None)
+                     for st, (x, y) in zip(starts, finals)}
     for side in "ab":
         p = os.path.join(d, side, "notify")
         out[side + "_notify"] = open(p).read() if os.path.exists(p) else ""
