@@ -22,7 +22,9 @@
 
 typedef unsigned long long u64;
 
-#define QK_WAVES 4            /* wavefronts per workgroup */
+#ifndef QK_WAVES
+#define QK_WAVES 4            /* wavefronts per workgroup (2 and 8 measured: see DESIGN.md) */
+#endif
 #define QK_THREADS (QK_WAVES * 64)
 #define QK_IDX_PAD 64         /* ints of padding after cn_tr / cn_var so unconditional index reads stay in bounds */
 
