@@ -78,4 +78,9 @@ PY
 cp "$ROOT/qcrypto-ldpc_amd/host/ldpc_reconcile.c" "$ROOT/qcrypto-ldpc_amd/host/ldpc_reconcile.h" subcomponents/
 gcc -O2 -g -w -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc" $SRCS subcomponents/ldpc_reconcile.c \
     -L"$ROOT/qcrypto-ldpc_amd" -lqldpc -Wl,-rpath,'$ORIGIN/../../qcrypto-ldpc_amd' -Wl,-rpath,/opt/rocm/lib -lm
+# optional: the same LDPC daemon with AddressSanitizer on the C sources (host code only), for chasing memory errors: ECD2_ASAN=1
+if [ -n "${ECD2_ASAN:-}" ]; then
+  gcc -O1 -g -w -fsanitize=address -fno-omit-frame-pointer -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc_asan" $SRCS subcomponents/ldpc_reconcile.c \
+      -L"$ROOT/qcrypto-ldpc_amd" -lqldpc -Wl,-rpath,'$ORIGIN/../../qcrypto-ldpc_amd' -Wl,-rpath,/opt/rocm/lib -lm
+fi
 echo "built $OUT/ecd2_cascade and $OUT/ecd2_ldpc"

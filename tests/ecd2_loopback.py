@@ -30,7 +30,7 @@ def read_stream7(path):
     return dict(tag=tag, epoch=epoch, nepochs=nepochs, nbits=nbits, words=words)
 
 
-def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180, blocks=None, cmd_gaps=(3.0, 0.06)):
+def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180, blocks=None, cmd_gaps=(60.0, 0.25)):
     """alice_bits / bob_bits: lists of per-epoch 0/1 arrays. Returns dict with both final keys + logs.
     blocks: epochs per command (default: one command = one block of all epochs); with several commands written at once
     several blocks are in flight, and out["finals"] maps each block's first epoch to its (alice, bob) stream-7 files."""
@@ -70,8 +70,13 @@ def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_e
             for i, (st, nb) in enumerate(zip(starts, blocks_)):
                 f.write("0x%08x %d\n" % (st, nb))
                 f.flush()
-                if len(blocks_) > 1:
-                    time.sleep(cmd_gaps[0] if i == 0 else cmd_gaps[1])
+                if len(blocks_) > 1 and i == 0:      # first block: wait until it is through (GPU start-up, code construction), at most cmd_gaps[0]
+                    tw = time.time()
+                    while time.time() - tw < cmd_gaps[0] and not all(os.path.exists(x) for x in
+                                                                     (os.path.join(d, "a", "final", "%08x" % st), os.path.join(d, "b", "final", "%08x" % st))):
+                        time.sleep(0.05)
+                elif len(blocks_) > 1:
+                    time.sleep(cmd_gaps[1])
         fa = os.path.join(d, "a", "final", "%08x" % epoch0)
         fb = os.path.join(d, "b", "final", "%08x" % epoch0)
         finals = [(os.path.join(d, "a", "final", "%08x" % st), os.path.join(d, "b", "final", "%08x" % st)) for st in starts]

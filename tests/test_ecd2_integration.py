@@ -17,6 +17,13 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 
 def epochs(seed, n_epochs, bits_per_epoch, qber):
+    """Per-epoch sifted keys.  Block sizes are kept off multiples of 32 bits: the reference's QBER sampling loops accept the
+    position `initialBits` itself (`if (bipo > processBlock->initialBits) continue;`, subcomponents/comms.c:80 and
+    qber_estim.c:190 -- should be >=); when initialBits is a multiple of 32 that position's marker word is the first word of
+    the uninitialised permuteIndex array (processblock_mgmt.c:146-156 clears only `newindex` words), so Alice and Bob may or
+    may not skip it depending on heap junk and their sample positions desynchronise (seen as 20-40 % "QBER" on later blocks
+    of a daemon that has reused heap memory).  Not ours to fix; the tests steer around it."""
+    assert (n_epochs * bits_per_epoch) % 32 != 0
     rng = np.random.default_rng(seed)
     a = [rng.integers(0, 2, bits_per_epoch).astype(np.uint8) for _ in range(n_epochs)]
     b = [x ^ (rng.random(bits_per_epoch) < qber) for x in a]
@@ -43,7 +50,7 @@ def test_plugin_compiles_against_the_reference_headers():
 def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
     """pristine reference daemon: both sides end with the same stream-7 key."""
     binary = need("ecd2_cascade")
-    a, b = epochs(1, 4, 4000, 0.02)
+    a, b = epochs(1, 4, 4001, 0.02)
     out = run_loopback(binary, tmp_path, a, b)
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + out["b_log"][-2000:]
     assert out["a_final"]["tag"] == 7 and out["a_final"]["nbits"] == out["b_final"]["nbits"] > 4000
@@ -51,7 +58,7 @@ def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_epochs,bits,qber", [(4, 4000, 0.02), (4, 15000, 0.02), (2, 9000, 0.03)])
+@pytest.mark.parametrize("n_epochs,bits,qber", [(4, 4001, 0.02), (4, 15001, 0.02), (2, 9000, 0.03)])
 def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
     """ECD2_LDPC=1: Bob (QBER follower) picks ALG_LDPC_CONTINUE_ROLES; one parity packet + one verdict instead of
     ~55 cascade packets each way; both daemons write identical final keys."""
@@ -79,7 +86,7 @@ def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
     Alice hashes on her GPU, Bob on his: equal stream-7 files prove the GPU hash equals itself across processes AND,
     through the CPU run below with the SAME daemons, that it is the reference's hash."""
     binary = need("ecd2_ldpc")
-    a, b = epochs(5, 4, 15000, 0.02)
+    a, b = epochs(5, 4, 15001, 0.02)
     gpu = run_loopback(binary, tmp_path / "gpu", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"})
     assert gpu["a_final"] is not None and (gpu["a_final"]["words"] == gpu["b_final"]["words"]).all()
     # Bob on the GPU hash, Alice on the reference's CPU loop: the two final keys must still be identical
@@ -120,7 +127,7 @@ def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
 @pytest.mark.gpu
 def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
     """same epochs through both daemons: both reconcile; LDPC leaks M+32 bits, cascade its parity count."""
-    a, b = epochs(3, 4, 6000, 0.02)
+    a, b = epochs(3, 4, 6001, 0.02)
     o1 = run_loopback(need("ecd2_cascade"), tmp_path / "c", a, b)
     o2 = run_loopback(need("ecd2_ldpc"), tmp_path / "l", a, b, env_extra={"ECD2_LDPC": "1"})
     for o in (o1, o2):
@@ -135,7 +142,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
     daemons finish the block with the reference's own cascade exchange. The final keys are identical, and the wasted
     parity + CRC bits stay in leakageBits."""
     binary = need("ecd2_ldpc")
-    a, b = epochs(7, 4, 6000, 0.02)
+    a, b = epochs(7, 4, 6001, 0.02)
     clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"})
     out = run_loopback(binary, tmp_path / "fault", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_LDPC_FAULT": "600"})
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
@@ -167,15 +174,23 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
     daemons produce for the same epochs."""
     binary = need("ecd2_ldpc")
     rng = np.random.default_rng(17)
-    sizes = [3000, 3400, 3100, 3300, 3000, 3500, 3200, 3050] * 2                  # 16 epochs, 2 per block -> 8 blocks of 6 100 .. 6 550 bits
+    # 16 epochs, 2 per block -> 8 blocks of 6 260 .. 6 507 bits, none a multiple of 32 (see epochs()); QBER 3 % so that the
+    # reference's first 411-bit sample practically never shows so few errors that it asks for more test bits than the block
+    # has and terminates it (at 2 % that happens to 1 block in 100)
+    sizes = [3001, 3410, 3107, 3311, 3005, 3502, 3203, 3057] * 2
+    assert all((sizes[i] + sizes[i + 1]) % 32 for i in range(0, 16, 2))
     a = [rng.integers(0, 2, n).astype(np.uint8) for n in sizes]
-    b = [x ^ (rng.random(x.size) < 0.02) for x in a]
+    b = [x ^ (rng.random(x.size) < 0.03) for x in a]
     env = {"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"}
-    one = run_loopback(binary, tmp_path / "one", a, b, env_extra=env, blocks=[2] * 8, timeout=40)
-    env_b = dict(env, ECD2_LDPC_BATCH="4", ECD2_LDPC_BATCH_WAIT_MS="300")
-    bat = run_loopback(binary, tmp_path / "batch", a, b, env_extra=env_b, blocks=[2] * 8, timeout=40)
+    one = run_loopback(binary, tmp_path / "one", a, b, env_extra=env, blocks=[2] * 8, timeout=90)
+    env_b = dict(env, ECD2_LDPC_BATCH="4", ECD2_LDPC_BATCH_WAIT_MS="1500")
+    bat = run_loopback(binary, tmp_path / "batch", a, b, env_extra=env_b, blocks=[2] * 8, timeout=90)
     for name, o in (("one", one), ("batch", bat)):
         missing = [hex(st) for st, (x, y) in o["finals"].items() if x is None or y is None]
+        if missing:      # keep the daemons' logs where gpurun brings them back
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            for side in "ab":
+                open(os.path.join(ROOT, "gpurun_out", "ecd2_stuck_%s_%s.log" % (name, side)), "w").write(o[side + "_log"])
         assert not missing and o["elapsed"] < 60, (name, missing, o["elapsed"], o["a_log"][-1500:], o["b_log"][-1500:])
     assert len(bat["finals"]) == 8
     for st, (fa, fb) in bat["finals"].items():

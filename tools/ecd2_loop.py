@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Developer loop: the multi-block two-daemon loopback many times, to chase intermittent failures (run on the GPU box).
+usage: ecd2_loop.py <binary name under oracle/_ref> <runs> [ENV=VAL ...]"""
+import os
+import pathlib
+import re
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ecd2_loopback import run_loopback  # noqa: E402
+
+binary = os.path.join(ROOT, "oracle", "_ref", sys.argv[1])
+runs = int(sys.argv[2])
+env = {"ECD2_LDPC": "1"}
+for kv in sys.argv[3:]:
+    k, v = kv.split("=", 1)
+    env[k] = v
+bad = 0
+for trial in range(runs):
+    rng = np.random.default_rng(17)
+    sizes = [3001, 3410, 3107, 3311, 3005, 3502, 3203, 3057] * 2      # block sizes off multiples of 32, see tests/test_ecd2_integration.py:epochs
+    a = [rng.integers(0, 2, n).astype(np.uint8) for n in sizes]
+    b = [x ^ (rng.random(x.size) < 0.03) for x in a]
+    d = pathlib.Path(tempfile.mkdtemp())
+    out = run_loopback(binary, d, a, b, env_extra=env, blocks=[2] * 8, timeout=40)
+    missing = [hex(k) for k, v in out["finals"].items() if v[0] is None or v[1] is None]
+    if missing:
+        bad += 1
+        first = [l for l in out["b_log"].splitlines() if "qber_processReceivedQberEstBits" in l][-1]
+        print(trial, "missing", missing, "|", re.sub(r"\s+", " ", first), flush=True)
+        for side in "ab":
+            open(os.path.join(ROOT, "gpurun_out", "loop_fail_%s.log" % side), "w").write(out[side + "_log"])
+print("%s %s: %d of %d runs failed" % (sys.argv[1], env, bad, runs), flush=True)
