@@ -208,20 +208,32 @@ __device__ __forceinline__ float qk_rcp(float x) { return __builtin_amdgcn_rcpf(
 __device__ __forceinline__ float qk_tanh_half(float a) { const float e = __expf(-a); return (1.0f - e) * qk_rcp(1.0f + e); }
 __device__ __forceinline__ float qk_2atanh(float r) { return __logf((1.0f + r) * qk_rcp(1.0f - r)); }
 
-/* messages enter the SPA fold as sign-carrying tanh(|x|/2) so the value is computed once per edge */
+/*
+ * SPA on exponentials (three transcendentals per edge instead of five).  With e_i = exp(-|x_i|), tanh(|x_i|/2) =
+ * (1 - e_i) / (1 + e_i), so the product over the other edges is Nn / D with
+ *   Nn = P_num * (1 + e_i),  D = P_den * (1 - e_i),   P_num = prod (1 - e_j),  P_den = prod (1 + e_j)   (all j)
+ * and 2 atanh(Nn / D) = ln((D + Nn) / (D - Nn)): one exp on the way in, one rcp and one log on the way out, no division
+ * by tanh_i.  AFF3CT's clamp of the product to 1 - FLT_EPSILON becomes a clamp of the ratio to (2 - eps) / eps; the
+ * comparison is written so that NaN (an erased edge: 0 / 0, which AFF3CT's `v < 1 ? v : 1 - eps` also sends to the
+ * clamp) takes it too.  Messages enter the fold as sign-carrying e_i so the exponential is computed once per edge.
+ * P_den <= 2^dc stays finite in fp32 for check degrees below 128.
+ */
+#define QK_SPA_RMAX 16777215.0f      /* (2 - eps) / eps with eps = 2^-23 */
 template <int FAM> __device__ __forceinline__ float qk_prep(float x) { return x; }
-template <> __device__ __forceinline__ float qk_prep<QK_FAM_SPA>(float x) { return qk_withsign(qk_tanh_half(fabsf(x)), qk_bits(x)); }
+template <> __device__ __forceinline__ float qk_prep<QK_FAM_SPA>(float x) { return qk_withsign(__expf(-fabsf(x)), qk_bits(x)); }
 
 template <> struct qk_acc<QK_FAM_SPA> {
-    uint32_t sign; float product;
-    __device__ __forceinline__ void begin() { sign = 0; product = 1.0f; }
-    __device__ __forceinline__ void in(float xp) { sign ^= qk_bits(xp); product *= fabsf(xp); }      /* xp = qk_prep(x) */
+    uint32_t sign; float pnum, pden;
+    __device__ __forceinline__ void begin() { sign = 0; pnum = 1.0f; pden = 1.0f; }
+    __device__ __forceinline__ void in(float xp) { const float e = fabsf(xp); sign ^= qk_bits(xp); pnum *= 1.0f - e; pden *= 1.0f + e; }      /* xp = qk_prep(x) */
     __device__ __forceinline__ void finish(const qk_rule &) {}
     __device__ __forceinline__ float out(float xp, const qk_rule &) const
     {
-        float t = product * qk_rcp(fabsf(xp));
-        t = (t < 1.0f) ? t : 1.0f - 1.1920928955078125e-07f;
-        return qk_withsign(qk_2atanh(t), sign ^ qk_bits(xp));
+        const float e = fabsf(xp);
+        const float nn = pnum * (1.0f + e), d = pden * (1.0f - e);
+        float r = (d + nn) * qk_rcp(d - nn);
+        r = (r < QK_SPA_RMAX) ? r : QK_SPA_RMAX;
+        return qk_withsign(__logf(r), sign ^ qk_bits(xp));
     }
 };
 
