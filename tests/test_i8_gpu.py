@@ -209,3 +209,27 @@ def test_layered_fixed_point_irregular_and_syndrome_form(q, O, torch):
     assert (hard == ref["hard"]).all() and (it.cpu().numpy() == ref["iters"]).all() and (ok.cpu().numpy() == ref["synd_ok"]).all()
     good = ok.cpu().numpy() == 1
     assert good.mean() > 0.2 and (hard[good] == x[good]).all()          # all N VNs are channel VNs here: a hard point for rate 0.94
+
+
+def test_layered_fixed_point_runs_the_references_matlab_experiment(q, O, torch, gold):
+    """The reference's fixed-point MATLAB decoder experiment (tests/matlab_fp.py; sim_results.m:8-13) on the GPU: NR_2_6_52 at
+    rate 1/2, 6-bit quantised AWGN LLRs, layered offset-min-sum, offset 2, 20 sweeps.  Bit-exact against the integer oracle
+    (which equals a literal restatement of the MATLAB loop, tests/test_oracle.py), and the published frame-error rate at
+    2.35 dB (54 / 20 000) comes out of 20 000 frames here."""
+    import matlab_fp
+    name = "NR_2_6_52"
+    path = os.path.join(gold, matlab_fp.PINS[name]["qc"])
+    code, og = q.Code.from_qc(path), O.Graph.from_qc(path)
+    assert code.layer_order()[2]                                         # natural order: the base rows are the layers, as in the script
+    dec = q.Decoder(code, code.N, matlab_fp.MAX_ITRS, rule="OMS", rule_param=matlab_fp.OFFSET, n_frames=20000, schedule="hlayered",
+                    enable_syndrome=False, msg_dtype="i8", quant_scale=1.0)
+    x, rq, k = matlab_fp.frames(name, 1.5, 700, np.random.default_rng(8))
+    ref = O.decode(og, rq, "OMS", matlab_fp.OFFSET, matlab_fp.MAX_ITRS, "hlayered", enable_syndrome=False, n_threads=8, msg_i8=True, quant_scale=1.0)
+    hard, _, _, post = run(q, torch, dec, rq, True)
+    assert (post == ref["post"]).all() and (hard == ref["hard"]).all()
+    x, rq, k = matlab_fp.frames(name, 2.35, 20000, np.random.default_rng(9))
+    hard, _, _, _ = run(q, torch, dec, rq, False)
+    errs = int((hard[:, :k] != 0).any(1).sum())
+    lo, hi = matlab_fp.band(name, 2.35, 20000)
+    print("NR_2_6_52 @ 2.35 dB: %d frame errors of 20000 (published 54 of 20000)" % errs)
+    assert lo <= errs / 20000.0 <= hi

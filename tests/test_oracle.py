@@ -153,3 +153,65 @@ def test_fixed_point_quantiser_and_rules(O, peg):
     r = O.decode(peg, llr, "NMS", 0.75, 1, enable_syndrome=False, msg_i8=True, quant_scale=4.0)
     m = (10 * 96) >> 7                                                    # 7
     assert set(np.unique(r["post"][0]).tolist()) == {10 + 3 * m, 10 + m, -10 + 3 * m}   # untouched VNs, neighbours of the flipped VN's checks, the flipped VN
+
+
+@pytest.mark.parametrize("ebno,F", [(1.0, 600), (1.5, 1500), (2.0, 4000)])
+def test_fixed_point_layered_decoder_reproduces_the_references_matlab_fer(O, gold, ebno, F):
+    """Statistical pin for the integer layered decoder (the 8-bit GPU variant's oracle): the frame-error rates the reference
+    publishes for its fixed-point layered offset-min-sum MATLAB decoder (sim_results.m:8-13: NR_2_6_52 at rate 1/2, 20
+    iterations, offset 2, 6-bit messages / 8-bit posteriors) on the same matrix, channel, puncturing and quantiser
+    (tests/matlab_fp.py says which message choice reproduces the table)."""
+    import matlab_fp
+    name = "NR_2_6_52"
+    g = O.Graph.from_qc(os.path.join(gold, matlab_fp.PINS[name]["qc"]))
+    x, rq, k = matlab_fp.frames(name, ebno, F, np.random.default_rng(int(ebno * 10) + F))
+    r = O.decode(g, rq, "OMS", matlab_fp.OFFSET, matlab_fp.MAX_ITRS, "hlayered", enable_syndrome=False, n_threads=8, msg_i8=True, quant_scale=1.0)
+    fer = float((r["hard"][:, :k] != x[:, :k]).any(1).mean())
+    lo, hi = matlab_fp.band(name, ebno, F)
+    print("%s Eb/N0 %.2f dB: FER %.4f (published %.4f, band %.4f..%.4f)" % (name, ebno, fer, matlab_fp.published(name, ebno)["fer"], lo, hi))
+    assert lo <= fer <= hi
+    assert np.abs(r["post"]).max() <= 127
+
+
+def test_fixed_point_layered_decoder_equals_a_literal_restatement_of_the_matlab_loop(O, gold):
+    """The same recursion written the way the MATLAB script writes it (block rows, mul_sh rotations, R storage per base
+    entry, [-32, 31] / [-128, 127] clamps) in numpy: identical posteriors, so the symmetric clamps of the integer decoder
+    change nothing on this workload."""
+    import matlab_fp
+    name = "NR_2_6_52"
+    p = matlab_fp.PINS[name]
+    z, nb, mb = p["z"], p["nb_rm"], p["mb_rm"]
+    B = np.array([l.split() for l in open(os.path.join(gold, p["qc"])) if l.strip()][1:], dtype=int)
+    x, rq, k = matlab_fp.frames(name, 1.5, 120, np.random.default_rng(3))
+    F = rq.shape[0]
+    rot = lambda a, s: np.concatenate([a[:, s % z:], a[:, :s % z]], axis=1)      # mul_sh
+    L = rq.astype(np.int64).copy()
+    R = np.zeros((int((B != -1).sum()), F, z), np.int64)
+    for _ in range(matlab_fp.MAX_ITRS):
+        Ri = 0
+        for lyr in range(mb):
+            cols = [c for c in range(nb) if B[lyr, c] != -1]
+            treg = []
+            for c in cols:
+                L[:, c * z:(c + 1) * z] -= R[Ri]
+                treg.append(np.clip(rot(L[:, c * z:(c + 1) * z], B[lyr, c]), -32, 31))
+                Ri += 1
+            T = np.stack(treg)
+            A = np.abs(T)
+            pos = A.argmin(0)
+            min1 = A.min(0)
+            A2 = A.copy()
+            np.put_along_axis(A2, pos[None], 10 ** 9, 0)
+            min2 = A2.min(0)
+            S = np.where(T >= 0, 1, -1)
+            out = np.broadcast_to(np.maximum(min1 - 2, 0), T.shape).copy()
+            np.put_along_axis(out, pos[None], np.maximum(min2 - 2, 0)[None], 0)
+            out = S.prod(0)[None] * S * out
+            Ri -= len(cols)
+            for ti, c in enumerate(cols):
+                R[Ri] = rot(out[ti], z - B[lyr, c])
+                L[:, c * z:(c + 1) * z] = np.clip(L[:, c * z:(c + 1) * z] + R[Ri], -128, 127)
+                Ri += 1
+    g = O.Graph.from_qc(os.path.join(gold, p["qc"]))
+    r = O.decode(g, rq, "OMS", 2.0, matlab_fp.MAX_ITRS, "hlayered", enable_syndrome=False, n_threads=8, msg_i8=True, quant_scale=1.0)
+    assert (r["post"] == L).all()
