@@ -215,3 +215,48 @@ def test_fixed_point_layered_decoder_equals_a_literal_restatement_of_the_matlab_
     g = O.Graph.from_qc(os.path.join(gold, p["qc"]))
     r = O.decode(g, rq, "OMS", 2.0, matlab_fp.MAX_ITRS, "hlayered", enable_syndrome=False, n_threads=8, msg_i8=True, quant_scale=1.0)
     assert (r["post"] == L).all()
+
+
+def test_float_layered_min_sum_follows_the_references_matlab_recursion(O, gold):
+    """decode_hlayered (the float horizontal-layered schedule) against a numpy restatement, in double precision, of the loop
+    the reference keeps in MATLAB (BPSK_nrldpc_sim.m:29-69: L = L - R, min1 / min2 / parity per row, R = new, L = L + R,
+    one base row per layer, all-zero word over AWGN, 8 sweeps): same decisions, posteriors equal to float32 accuracy."""
+    import matlab_fp
+    p = matlab_fp.PINS["NR_2_6_52"]
+    z, nb, mb = p["z"], p["nb_rm"], p["mb_rm"]
+    B = np.array([l.split() for l in open(os.path.join(gold, p["qc"])) if l.strip()][1:], dtype=int)
+    rng = np.random.default_rng(12)
+    F, n = 150, nb * z
+    r = (1.0 + 0.75 * rng.standard_normal((F, n))).astype(np.float32)
+    rot = lambda a, s: np.concatenate([a[:, s % z:], a[:, :s % z]], axis=1)
+    L = r.astype(np.float64).copy()
+    R = np.zeros((int((B != -1).sum()), F, z))
+    for _ in range(8):
+        Ri = 0
+        for lyr in range(mb):
+            cols = [c for c in range(nb) if B[lyr, c] != -1]
+            treg = []
+            for c in cols:
+                L[:, c * z:(c + 1) * z] -= R[Ri]
+                treg.append(rot(L[:, c * z:(c + 1) * z], B[lyr, c]))
+                Ri += 1
+            T = np.stack(treg)
+            A = np.abs(T)
+            pos = A.argmin(0)
+            min1 = A.min(0)
+            A2 = A.copy()
+            np.put_along_axis(A2, pos[None], np.inf, 0)
+            min2 = A2.min(0)
+            S = np.sign(T)
+            out = np.broadcast_to(min1, T.shape).copy()
+            np.put_along_axis(out, pos[None], min2[None], 0)
+            out = S.prod(0)[None] * S * out
+            Ri -= len(cols)
+            for ti, c in enumerate(cols):
+                R[Ri] = rot(out[ti], z - B[lyr, c])
+                L[:, c * z:(c + 1) * z] += R[Ri]
+                Ri += 1
+    g = O.Graph.from_qc(os.path.join(gold, p["qc"]))
+    ref = O.decode(g, r, "MS", 0.0, 8, "hlayered", enable_syndrome=False, n_threads=8)
+    assert np.allclose(ref["post"], L, rtol=2e-4, atol=2e-4)
+    assert ((ref["hard"] == 1) == (L < 0)).mean() > 0.9999
