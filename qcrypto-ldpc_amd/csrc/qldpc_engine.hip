@@ -158,7 +158,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
-    (void)hipFree(d->d_sgn); (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
+    (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
     if (d->h_done) (void)hipHostFree(d->h_done);
@@ -294,7 +294,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         if ((rc = dev_alloc(d, &d->d_b, G * d->E * FG))) return rc;
     }
     if ((rc = dev_alloc(d, &d->d_sgn, G * d->N * V))) return rc;
-    if ((rc = dev_alloc(d, &d->d_hard, G * d->N * V))) return rc;
+    if (d->msg_i8) d->d_hard = d->d_sgn;      /* integer posteriors: signbit(post) and !(post >= 0) are the same ballot */
+    else if ((rc = dev_alloc(d, &d->d_hard, G * d->N * V))) return rc;
     if ((rc = dev_alloc(d, &d->d_unsat, G * V))) return rc;
     if ((rc = dev_alloc(d, &d->d_done, G * V))) return rc;
     if ((rc = dev_alloc(d, &d->d_depth, G * FG))) return rc;
@@ -533,7 +534,7 @@ static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
     if (d->msg_i8) {
         if constexpr (V == QI_V) {
             dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
-            hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, d->d_hard,
+            hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
                                post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done);
         }
         return;
@@ -648,7 +649,7 @@ static int run_layered(qldpc_decoder *d)
     HIPCHK(hipMemcpyAsync(d->d_a, d->msg_i8 ? (const void *)d->d_llr8 : (const void *)d->d_llr, G * d->N * FG * cell, hipMemcpyDeviceToDevice, d->stream));   /* var_nodes = Y_N */
     HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));                                                                                       /* messages = 0   */
     auto ballots = [&]() {
-        if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+        if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr, d->N, d->d_done);
         else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
     };
     int ite = 0;

@@ -241,16 +241,20 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             }
         }
     }
+    /* all UN x 4 ballot words of the wavefront leave in one store instruction (lane 4u + j carries ballot j of VN u);
+     * hard == NULL: the decoder aliases it to sgn, an integer posterior has one sign */
+    u64 mine = 0;
+    u64 *dst = sgn;
 #pragma unroll
     for (int u = 0; u < UN; u++) {
         const short t[QI_V] = {tl[u].x, tl[u].y, th[u].x, th[u].y};
+        const size_t b0 = ((size_t)g * N + vv[u]) * QI_V;
 #pragma unroll
         for (int j = 0; j < QI_V; j++) {
             u64 s = __ballot(t[j] < 0);
-            const size_t bi = ((size_t)g * N + vv[u]) * QI_V + j;
             const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * QI_V + j];
-            if (dm) s = (s & ~dm) | (sgn[bi] & dm);       /* converged frames keep the ballots they converged with */
-            if (lane == 0) { sgn[bi] = s; hard[bi] = s; }
+            if (dm) s = (s & ~dm) | (sgn[b0 + j] & dm);       /* converged frames keep the ballots they converged with */
+            if (lane == u * QI_V + j) { mine = s; dst = sgn + b0 + j; }
         }
         if constexpr (MODE == QK_VN_POST) {
             if (post_out) {
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             }
         }
     }
+    if (lane < UN * QI_V) { *dst = mine; if (hard) hard[dst - sgn] = mine; }
 }
 
 /* ------------------------------------------------------------------ horizontal layered ------- */
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_post_ballots(const uint32_t *__
             const size_t bi = ((size_t)g * N + v) * QI_V + j;
             const u64 dm = done[(size_t)g * QI_V + j];
             if (dm) s = (s & ~dm) | (sgn[bi] & dm);
-            if (lane == 0) { sgn[bi] = s; hard[bi] = s; }
+            if (lane == 0) { sgn[bi] = s; if (hard) hard[bi] = s; }
         }
     }
 }
