@@ -27,6 +27,12 @@
  *                                         Encoder_LDPC_from_H(K,N,H,"IDENTITY",...)  VAR/main.cpp (alist-v1.0.1):142-145
  *   qldpc_min_code_rate, qldpc_parity_bits_to_punct   min_cr(), parity_bits_to_punct()   BS/src/main.cpp:23-34
  *   packed-bit layout (bit i <-> word[i/32] & (1u << (31 - i%32)))                  subcomponents/helpers.h:65-70
+ *   qldpc_code_ira_peg / qldpc_code_qc_peg   ldpc_examples/improved-peg.py:136-195 / psd-peg.py:281-447 (H-matrix construction)
+ *   qldpc_decoder_cfg.msg_dtype = 2       the fixed-point layered min-sum of ldpc_examples/.../BPSK_nrldpc_sim_RM_FP.m:37-98
+ *   qldpc_recon_* (sessions)              what the two `return 81` arms of subcomponents/qber_estim.c:337-340,420-423 need:
+ *                                         rate choice (BS/src/main.cpp:29,235-266), frame formation, verification; bound by
+ *                                         qcrypto-ldpc_amd/host/ldpc_reconcile.c (packet handlers, cascade fallback, batched ingest)
+ *   qldpc_privamp*                        the hash loop of privAmp_doPrivAmp         subcomponents/priv_amp.c:190-218
  */
 #ifndef QLDPC_H
 #define QLDPC_H
