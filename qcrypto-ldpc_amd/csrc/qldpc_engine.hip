@@ -186,7 +186,9 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     d->V = V; d->FG = 64 * V; d->G = (cfg->max_frames + d->FG - 1) / d->FG;
     d->freeze = cfg->freeze_messages ? 1 : 0;
     if (const char *e = getenv("QLDPC_FREEZE")) d->freeze = atoi(e) ? 1 : 0;
-    d->poll_every = d->G >= 8 ? 2 : 0;
+    /* early exit: the host looks at the active-group counter every 2 iterations once an iteration is long enough to hide the
+     * ~30 us round trip (>= 2e7 message updates); small decodes run their iterations as early-returning launches instead */
+    d->poll_every = (d->G >= 8 || (double)d->E * d->G * d->FG >= 2e7) ? 2 : 0;
     if (const char *e = getenv("QLDPC_POLL_EVERY")) d->poll_every = atoi(e);
 
     int rc;
