@@ -313,6 +313,10 @@ int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float 
                        const uint32_t *parity_words, int *corrected_bits, int *leaked_bits, int *iterations);
 /* Bob, n blocks that share one plan (same key_bits / rate / code dims) in one launch.
  * key_words[n][ceil(key_bits/32)], parity_words[n][ceil(code_m/32)], status[n] = QLDPC_OK / QLDPC_EDECODE. */
+/* Alice's side for many blocks of any mix of lengths / plans in one call: every msgs[i] is planned and filled as by
+ * qldpc_recon_encode, blocks are grouped by plan and encoded in launches of up to max_blocks frames. */
+int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *const *key_words, const int *key_bits, const float *qber,
+                              qldpc_recon_msg *msgs, uint32_t *const *parity_words, const int *parity_cap);
 int qldpc_recon_decode_batch(qldpc_recon *r, int n_blocks, uint32_t *key_words, int key_bits, const float *qber,
                              const qldpc_recon_msg *msgs, const uint32_t *parity_words, int *status,
                              int *corrected_bits, int *iterations);

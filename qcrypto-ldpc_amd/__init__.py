@@ -500,6 +500,7 @@ _sig("qldpc_recon_plan", C.c_int, [_vp, C.c_int, C.c_float, C.POINTER(ReconMsg)]
 _sig("qldpc_recon_encode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, C.c_int])
 _sig("qldpc_recon_decode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
 _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
+_sig("qldpc_recon_encode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip])
 _sig("qldpc_recon_decode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip, _ip, _ip])
 _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
 
@@ -576,6 +577,22 @@ class Recon:
                                          par.ctypes.data_as(_up), st.ctypes.data_as(_ip), co.ctypes.data_as(_ip),
                                          it.ctypes.data_as(_ip)), "Recon.decode_batch")
         return st, kw, co, it
+
+    def encode_blocks(self, keys, key_bits, qber):
+        """Alice's side for a list of blocks: returns (msgs, parities), one ReconMsg / uint32 array per block"""
+        n = len(keys)
+        kws = [np.ascontiguousarray(k, dtype=np.uint32) for k in keys]
+        kb = np.ascontiguousarray(key_bits, dtype=np.int32)
+        qb = np.ascontiguousarray(qber, dtype=np.float32)
+        plans = [self.plan(int(b), float(p)) for b, p in zip(kb, qb)]
+        pars = [np.zeros((int(m.code_m) + 31) // 32, np.uint32) for m in plans]
+        caps = np.array([p.size for p in pars], np.int32)
+        kp = (_up * n)(*[k.ctypes.data_as(_up) for k in kws])
+        pp = (_up * n)(*[p.ctypes.data_as(_up) for p in pars])
+        arr = (ReconMsg * n)()
+        _chk(_L.qldpc_recon_encode_blocks(self._h, n, kp, kb.ctypes.data_as(_ip), qb.ctypes.data_as(_fp), arr, pp, caps.ctypes.data_as(_ip)),
+             "Recon.encode_blocks")
+        return [arr[i] for i in range(n)], pars
 
     def decode_blocks(self, keys, key_bits, qber, msgs, parities):
         """blocks of any mix of lengths / plans: lists of per-block uint32 arrays; returns (status[], corrected keys, corrected[], iterations[])"""

@@ -222,6 +222,56 @@ extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int
     return QLDPC_OK;
 }
 
+/*
+ * Alice's side for many blocks at once: plans every block (msgs[i] is filled as by qldpc_recon_encode), groups the blocks by
+ * plan and encodes each group in launches of up to max_blocks frames.  parity_words[i] must hold ceil(code_m / 32) words
+ * (parity_cap[i] words are available).
+ */
+extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *const *key_words, const int *key_bits, const float *qber,
+                                         qldpc_recon_msg *msgs, uint32_t *const *parity_words, const int *parity_cap)
+{
+    if (!r || !key_words || !key_bits || !qber || !msgs || !parity_words || !parity_cap || n <= 0) return QLDPC_EINVAL;
+    int rc;
+    for (int i = 0; i < n; i++) {
+        if (!key_words[i] || !parity_words[i]) return QLDPC_EINVAL;
+        if ((rc = qldpc_recon_plan(r, key_bits[i], qber[i], &msgs[i]))) return rc;
+        if (parity_cap[i] < ((int)msgs[i].code_m + 31) / 32) { qldpc_set_error("recon_encode_blocks: parity buffer %d holds %d words, need %d", i, parity_cap[i], ((int)msgs[i].code_m + 31) / 32); return QLDPC_ESIZE; }
+    }
+    HIPCHK(hipSetDevice(r->cfg.device));
+    std::vector<char> taken((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        if (taken[(size_t)i]) continue;
+        std::vector<int> idx;
+        for (int j = i; j < n; j++)
+            if (!taken[(size_t)j] && msgs[j].code_k == msgs[i].code_k && msgs[j].code_m == msgs[i].code_m) { idx.push_back(j); taken[(size_t)j] = 1; }
+        const int K = (int)msgs[i].code_k, M = (int)msgs[i].code_m, N = K + M;
+        const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
+        recon_entry *e;
+        if ((rc = get_entry(r, K, M, &e))) return rc;
+        for (size_t at = 0; at < idx.size(); at += (size_t)r->cfg.max_blocks) {
+            const int m = (int)std::min(idx.size() - at, (size_t)r->cfg.max_blocks);
+            std::vector<uint32_t> info((size_t)m * Wk, 0u), cw((size_t)m * Wn);
+            for (int t = 0; t < m; t++) {
+                const int j = idx[at + (size_t)t], kb = key_bits[j], Wkey = (kb + 31) / 32;
+                uint32_t *f = info.data() + (size_t)t * Wk;
+                memcpy(f, key_words[j], sizeof(uint32_t) * (size_t)Wkey);
+                if (kb & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (kb & 31));
+            }
+            HIPCHK(hipMemcpy(e->d_bits, info.data(), sizeof(uint32_t) * info.size(), hipMemcpyHostToDevice));
+            if ((rc = qldpc_encode_packed_dev(e->enc, e->d_bits, e->d_out, m, nullptr))) return rc;
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemcpy(cw.data(), e->d_out, sizeof(uint32_t) * cw.size(), hipMemcpyDeviceToHost));
+            for (int t = 0; t < m; t++) {
+                const int j = idx[at + (size_t)t];
+                memset(parity_words[j], 0, sizeof(uint32_t) * (size_t)Wm);
+                memcpy(parity_words[j], cw.data() + (size_t)t * Wn + Wk, sizeof(uint32_t) * (size_t)(Wn - Wk));
+                msgs[j].crc32 = qldpc_crc32_words(key_words[j], key_bits[j]);
+            }
+        }
+    }
+    return QLDPC_OK;
+}
+
 /* blocks of ONE plan (same K, M), possibly of different length: one launch.  key[i] is decoded in place. */
 static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *key_bits, const float *qber, const qldpc_recon_msg *const *msgs,
                         const uint32_t *const *parity, int *const *status, int *const *corrected, int *const *iterations)

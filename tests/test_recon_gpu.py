@@ -138,6 +138,11 @@ def test_blocks_of_mixed_length_and_plan_in_one_call(q, max_blocks):
         a, b, _ = block(q, rng, kb, p)
         m, par = batch.encode(a, kb, p)
         keys.append(a); bobs.append(b); msgs.append(m); pars.append(par)
+    # Alice's side in one call gives what the per-block call gives
+    m2, p2 = batch.encode_blocks(keys, [s_[0] for s_ in spec], [s_[1] for s_ in spec])
+    for a_, b_, pa, pb in zip(msgs, m2, pars, p2):
+        assert (a_.rate_index, a_.key_bits, a_.code_k, a_.code_m, a_.crc32) == (b_.rate_index, b_.key_bits, b_.code_k, b_.code_m, b_.crc32)
+        assert (pa == pb).all()
     pars[2] = pars[2].copy(); pars[2][::3] ^= 0x5a5a5a5a                            # this block must fail, alone
     assert len({(m.code_k, m.code_m) for m in msgs[:4] + msgs[8:]}) == 1 and msgs[4].code_m != msgs[0].code_m
     st, fixed, co, it = batch.decode_blocks(bobs, [s[0] for s in spec], [s[1] for s in spec], msgs, pars)
