@@ -218,6 +218,7 @@ def main():
     kstats = {s["name"]: s for s in dec.profile_read()}
     dec.profile(False)
     good, it_sum, n_all = verdicts(dec)
+    out_headline = out.clone()            # the later legs reuse `out`; the CPU cross-check below is about THIS leg
     value = good * K * args.steps / dt / 1e6
     fer = 1.0 - good / n_all
     if args.schedule != "flooding":          # experiment mode: one kernel family, no CPU / fp16 legs
@@ -292,7 +293,7 @@ def main():
         cpu, ref, ref_llr = cpu_baseline(code, llr_fn, args.rule, args.alpha, args.n_ite, K)
         # the same sample through the GPU must give the same words (cheap cross-check, not timed)
         nref = ref["hard"].shape[0]
-        got = q.unpack_bits(out[:nref].cpu().numpy().view(np.uint32), N)
+        got = q.unpack_bits(out_headline[:nref].cpu().numpy().view(np.uint32), N)
         cpu["gpu_matches_oracle_on_sample"] = bool((got == ref["hard"]).all())
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
