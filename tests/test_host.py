@@ -38,6 +38,26 @@ def test_scalar_helpers_follow_the_harness_macros(q):
     assert abs(q.min_code_rate(0.02, 1.0) - 0.8761) < 5e-4
 
 
+def test_rate_and_efficiency_helpers_reproduce_the_references_table(q):
+    """errorcorrection/README_LDPC.md:901-935, the reconciliation-efficiency table: the "Shannon Limit" rows are CR = min_cr(q, 1)
+    and K = 1 - 2 h(q); the DVB rows are f = ((1 - R) / R) / h(q) and K = (1 - FER) (1 - (1 - R) / R - h(q)).  (The two DVB rows printed under
+    BER 0.01 repeat the BER 0.02 values -- 37/45 at 1 % would be f = 2.68 -- and are left out.)"""
+    shannon = [(0.01, 0.9252, 0.8384), (0.02, 0.8761, 0.7171), (0.03, 0.8372, 0.6112), (0.04, 0.8050, 0.5154), (0.05, 0.7774, 0.4272),
+               (0.06, 0.7533, 0.3451), (0.07, 0.7321, 0.2682), (0.08, 0.7132, 0.1956), (0.09, 0.6962, 0.1271), (0.10, 0.6807, 0.0620), (0.11, 0.6667, 0.0002)]
+    for p, cr, k in shannon:
+        assert abs(q.min_code_rate(p, 1.0) - cr) < 6e-5, p
+        assert abs(1.0 - 2.0 * q.binary_entropy(p) - k) < 6e-5, p
+    dvb = [(0.02, 37 / 45, 1.5287, 0.6423, 0), (0.03, 7 / 9, 1.4698, 0.5199, 0), (0.04, 59 / 81, 1.5390, 0.3848, 0), (0.05, 59 / 81, 1.3020, 0.2271, 10 / 30),
+           (0.05, 2 / 3, 1.7458, 0.2136, 0), (0.06, 2 / 3, 1.5270, 0.1726, 0), (0.07, 2 / 3, 1.3664, 0.1341, 0), (0.08, 2 / 3, 1.2432, 0.0978, 0),
+           (0.09, 2 / 3, 1.1456, 0.0233, 19 / 30), (0.09, 3 / 5, 1.5274, -0.1031, 0), (0.10, 3 / 5, 1.4215, -0.1357, 0)]
+    for p, R, f, k, fer in dvb:      # fer: the frame-error rate the table quotes next to the row; its K is then (1 - FER) K
+        ratio, h = (1.0 - R) / R, q.binary_entropy(p)
+        assert abs(ratio / h - f) < 6e-4, (p, R)
+        assert abs((1.0 - ratio - h) * (1.0 - fer) - k) < 6e-4, (p, R)
+        # and the table's own logic: a code can be used at QBER p with efficiency f iff its rate is <= min_cr(p, f)
+        assert R <= q.min_code_rate(p, f) + 1e-4
+
+
 def test_alist_graph_matches_oracle_graph(q, O, gold):
     p = os.path.join(gold, "PEGReg504x1008.alist")
     c, g = q.Code.from_alist(p), O.Graph.from_alist(p)
