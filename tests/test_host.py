@@ -58,6 +58,23 @@ def test_rate_and_efficiency_helpers_reproduce_the_references_table(q):
         assert R <= q.min_code_rate(p, f) + 1e-4
 
 
+def test_puncturing_arithmetic_reproduces_the_references_5g_table(q):
+    """errorcorrection/README_LDPC.md:937-974 (NR_1_0_2.qc: N = 136, K = 44, parity bits punctured to reach efficiency 1): for every
+    QBER row the printed number of punctured bits is parity_bits_to_punct(K, N, min_cr(QBER, 1)) rounded down, and the printed code
+    rate, reconciliation efficiency and key rate follow from it."""
+    N, K = 136, 44
+    rows = [(0.01, 88, 1.12521, 0.828298, 0.916667), (0.02, 85, 1.12479, 0.699469, 0.862745), (0.03, 83, 1.05223, 0.601063, 0.830189),
+            (0.04, 81, 1.03181, 0.507708, 0.8), (0.05, 79, 1.03163, 0.418149, 0.77193), (0.06, 77, 1.04112, 0.331646, 0.745763),
+            (0.07, 75, 1.05586, 0.247713, 0.721311), (0.08, 74, 1.01719, 0.18873, 0.709677), (0.09, 72, 1.04141, 0.108985, 0.6875),
+            (0.10, 71, 1.01765, 0.0537318, 0.676923), (0.11, 70, 1.00017, 8.40425e-05, 0.666667)]
+    for p, punct, f, key_rate, cr in rows:
+        n = q.parity_bits_to_punct(N, K, q.min_code_rate(p, 1.0))
+        assert n == punct, (p, n)
+        rate = K / (N - n)
+        ratio, h = (1.0 - rate) / rate, q.binary_entropy(p)
+        assert abs(rate - cr) < 2e-6 and abs(ratio / h - f) < 2e-4 and abs(1.0 - ratio - h - key_rate) < 2e-5, p
+
+
 def test_alist_graph_matches_oracle_graph(q, O, gold):
     p = os.path.join(gold, "PEGReg504x1008.alist")
     c, g = q.Code.from_alist(p), O.Graph.from_alist(p)
