@@ -74,6 +74,8 @@ struct qldpc_decoder {
     int has_synd;
     float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
+    /* coded channel LLRs (flooding, fp32 / binary16 messages, after qldpc_load_bits_*): no LLR array is read, see qk_coded_llr */
+    u64 *d_ybits; float *d_fmag; int *d_fnch; uint8_t *d_vcls; int llr_coded;
     int packed_h16;                  /* binary16 variant: use the packed check-node kernel when V == 2 (QLDPC_PACKED_H16=0 turns it off) */
     int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */
     uint32_t *d_llr8;                /* [G][N][256] quantised channel LLRs, four frames of a lane per dword */
@@ -157,7 +159,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
-    (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
+    (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
@@ -285,6 +287,13 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
         const size_t elems = d->msg_i8 ? (G * d->E * FG + 3) / 4 : (d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG);      /* floats of storage */
         if (d->msg_i8 && (rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
+        const char *coded_env = getenv("QLDPC_CODED_LLR");      /* =0: keep the fp32 LLR array on the load_bits path too (A/B measurements) */
+        if (!d->msg_i8 && !(coded_env && coded_env[0] == '0')) {
+            if ((rc = dev_alloc(d, &d->d_ybits, G * d->N * V))) return rc;
+            if ((rc = dev_alloc(d, &d->d_fmag, G * FG))) return rc;
+            if ((rc = dev_alloc(d, &d->d_fnch, G * FG))) return rc;
+            if ((rc = dev_alloc(d, &d->d_vcls, (size_t)d->N))) return rc;
+        }
         if ((rc = dev_alloc(d, &d->d_a, elems))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, elems))) return rc;
     } else if (d->msg_i8) {
@@ -526,8 +535,14 @@ template <int V, int CAP, int UNX, int MODE, typename MT>
 static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
 {
     dim3 grid((unsigned)grid_x(b.n, UNX), (unsigned)d->G);
-    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done);
+    if (d->llr_coded) {
+        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+        hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, true>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, (const float *)nullptr, (MT *)d->d_a, d->d_sgn, d->d_hard,
+                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c);
+        return;
+    }
+    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, false>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
+                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{});
 }
 template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
@@ -864,6 +879,7 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
     HIPCHK(hipSetDevice(d->device));
     d->n_frames = n_frames;
     d->has_synd = 0;
+    d->llr_coded = 0;
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
         HIPCHK(hipMemcpyAsync(d->d_llr, d_llr, sizeof(float) * (size_t)n_frames * d->N, hipMemcpyDeviceToDevice, d->stream));
@@ -910,6 +926,26 @@ extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bit
         hipLaunchKernelGGL(qe_load_bits, dim3((unsigned)std::min((d->N + 255) / 256, 256), (unsigned)n_frames), dim3(256), 0, d->stream, d_bits, d_llr_mag, d_vn_class,
                            d->d_llr, d->N, W, d_n_channel);
         LAUNCHCHK();
+        d->loaded = 1; d->ran = 0;
+        return QLDPC_OK;
+    }
+    d->llr_coded = 0;
+    if (d->d_ybits) {
+        /* flooding, fp32 / binary16 messages: keep the received bits as ballots and rebuild Y in the VN passes (qk_coded_llr) */
+        prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N / 8.0) * n_frames);
+        dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_load_syndrome<1>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d->d_ybits, d->N, W, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_load_syndrome<2>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d->d_ybits, d->N, W, n_frames); break;
+        default: hipLaunchKernelGGL((qk_load_syndrome<4>), grid, dim3(QK_THREADS), 0, d->stream, d_bits, d->d_ybits, d->N, W, n_frames); break;
+        }
+        LAUNCHCHK();
+        const int total = d->G * d->FG;
+        hipLaunchKernelGGL(qk_load_frame_consts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->stream, d_llr_mag, d_n_channel, d->d_fmag, d->d_fnch, n_frames, total, d->N);
+        LAUNCHCHK();
+        if (d_vn_class) HIPCHK(hipMemcpyAsync(d->d_vcls, d_vn_class, (size_t)d->N, hipMemcpyDeviceToDevice, d->stream));
+        else HIPCHK(hipMemsetAsync(d->d_vcls, 0, (size_t)d->N, d->stream));
+        d->llr_coded = 1;
         d->loaded = 1; d->ran = 0;
         return QLDPC_OK;
     }

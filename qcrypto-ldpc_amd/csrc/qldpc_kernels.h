@@ -408,13 +408,27 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
  * check_syndrome_soft tests) and hard = !(tmp >= 0) (what decode_siho outputs).
  * One wavefront handles UN list entries with every row load issued before the first use.
  */
-template <int V, int DVMAX, int UN, int MODE, typename MT>
+/*
+ * Channel LLRs of a QKD frame take three magnitudes (BS/src/main.cpp:348-362: the frame's ln((1-p)/p) at channel VNs, 23.03 at
+ * pinned VNs, 0 at punctured ones) and the sign is the received bit.  After qldpc_load_bits_* the flooding passes therefore do
+ * not read an LLR array at all (CODED = true): the received bits sit as one ballot word per VN (bit = lane, like sgn / hard),
+ * the class is a byte per VN, the magnitude and the shortening length a value per frame; Y is rebuilt in registers, the same
+ * float the array would hold.  N/8 bytes per frame and pass instead of 4 N, and the loads are scalar.
+ */
+struct qk_coded_llr {
+    const u64 *ybits;          /* [G][N][V] received bits as ballots                         */
+    const float *fmag;         /* [G*FG] |LLR| of a channel bit of each frame (padding: 1)  */
+    const int *fnch;           /* [G*FG] class-0 VNs at index >= fnch[f] are pinned (shortening) */
+    const uint8_t *vcls;       /* [N] VN class                                               */
+};
+
+template <int V, int DVMAX, int UN, int MODE, typename MT, bool CODED = false>
 __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__ c2v, const float *__restrict__ llr,
                                                           MT *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride,
-                                                          const u64 *__restrict__ done)
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{})
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -436,8 +450,25 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
 #pragma unroll
     for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
     float y[UN][V], tmp[UN][V];
+    if constexpr (CODED) {
+        float mg[V];
+        int nc[V];
 #pragma unroll
-    for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
+        for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int cls = coded.vcls[vv[u]];
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const bool bit = (coded.ybits[((size_t)g * N + vv[u]) * V + j] >> lane) & 1ull;
+                const float m = (cls == 0) ? (vv[u] < nc[j] ? mg[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
+                y[u][j] = bit ? -m : m;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
+    }
 
     if constexpr (MODE == QK_VN_FIRST) {
 #pragma unroll
@@ -831,6 +862,16 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
             qk_store<V>(dst + ((size_t)g * N + v) * FG + lane * V, o);
         }
     }
+}
+
+/* per-frame constants of the coded-LLR form: fmag[f] = |LLR| (1 for padding frames), fnch[f] = shortening length (N = none) */
+__global__ __launch_bounds__(256) void qk_load_frame_consts(const float *__restrict__ llr_mag, const int *__restrict__ n_channel,
+                                                            float *__restrict__ fmag, int *__restrict__ fnch, int n_frames, int total, int N)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total) return;
+    fmag[f] = f < n_frames ? llr_mag[f] : 1.0f;
+    fnch[f] = (f < n_frames && n_channel) ? n_channel[f] : N;
 }
 
 /* packed MSB-first syndrome words synd_bits[n_frames][Wm] -> per-check ballots synd[G][M][V] (bit = lane) */
