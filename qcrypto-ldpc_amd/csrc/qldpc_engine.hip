@@ -288,7 +288,9 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         const size_t elems = d->msg_i8 ? (G * d->E * FG + 3) / 4 : (d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG);      /* floats of storage */
         if (d->msg_i8 && (rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
         const char *coded_env = getenv("QLDPC_CODED_LLR");      /* =0: keep the fp32 LLR array on the load_bits path too (A/B measurements) */
-        if (!d->msg_i8 && !(coded_env && coded_env[0] == '0')) {
+        /* measured: the 8-bit VN pass gets slower with coded LLRs (5.54 vs 6.0 TB/s: four ballot words and selects per VN to save one
+         * of nine bytes), so it keeps its quantised LLR array unless QLDPC_CODED_LLR=1 asks otherwise */
+        if (!(coded_env && coded_env[0] == '0') && (!d->msg_i8 || (coded_env && coded_env[0] == '1'))) {
             if ((rc = dev_alloc(d, &d->d_ybits, G * d->N * V))) return rc;
             if ((rc = dev_alloc(d, &d->d_fmag, G * FG))) return rc;
             if ((rc = dev_alloc(d, &d->d_fnch, G * FG))) return rc;
@@ -551,8 +553,13 @@ static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
     if (d->msg_i8) {
         if constexpr (V == QI_V) {
             dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
-            hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                               post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done);
+            if (d->llr_coded) {
+                qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+                hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, (const uint32_t *)nullptr, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale);
+            } else
+                hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f);
         }
         return;
     }

@@ -165,13 +165,20 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
 
 /* ------------------------------------------------------------------ variable nodes ----------- */
 
-template <int DVMAX, int UN, int MODE>
+__device__ __forceinline__ int qi_quant1(float llr, float scale)
+{
+    const float t = llr * scale;
+    return !(t < 127.0f) ? 127 : (t < -127.0f ? -127 : __float2int_rn(t));
+}
+
+/* CODED: the quantised channel LLRs are rebuilt from the received bits (qk_coded_llr, qldpc_kernels.h) instead of read from llr8 */
+template <int DVMAX, int UN, int MODE, bool CODED = false>
 __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__restrict__ c2v, const uint32_t *__restrict__ llr8,
                                                           uint32_t *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride /* dwords */,
-                                                          const u64 *__restrict__ done)
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f)
 {
     const int g = blockIdx.y;
     if (MODE != QK_VN_POST && qk_group_done<QI_V>(done, g)) return;
@@ -192,8 +199,27 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
 #pragma unroll
     for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
     uint32_t y[UN];
+    if constexpr (CODED) {
+        int qm[QI_V], nc[QI_V];
+        const int qpin = qi_quant1(23.025850929840455f, scale);
 #pragma unroll
-    for (int u = 0; u < UN; u++) y[u] = qi_ldm(yin + (size_t)vv[u] * 64);
+        for (int j = 0; j < QI_V; j++) { qm[j] = qi_quant1(coded.fmag[(size_t)g * QI_FG + lane * QI_V + j], scale); nc[j] = coded.fnch[(size_t)g * QI_FG + lane * QI_V + j]; }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int cls = coded.vcls[vv[u]];
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < QI_V; j++) {
+                const bool bit = (coded.ybits[((size_t)g * N + vv[u]) * QI_V + j] >> lane) & 1ull;
+                const int m = (cls == 0) ? (vv[u] < nc[j] ? qm[j] : qpin) : (cls == 1 ? qpin : 0);
+                w |= (uint32_t)((bit ? -m : m) & 0xff) << (8 * j);
+            }
+            y[u] = w;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UN; u++) y[u] = qi_ldm(yin + (size_t)vv[u] * 64);
+    }
     qi_s2 tl[UN], th[UN];
 
     if constexpr (MODE == QK_VN_FIRST) {
