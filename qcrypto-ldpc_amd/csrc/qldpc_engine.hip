@@ -450,10 +450,20 @@ static qi_rule qi_rule_of(const qldpc_decoder *d)
 }
 
 template <int V, int CAP, int FAM>
-static void launch_cn_one(qldpc_decoder *d, const bucket &b)
+static void launch_cn_one(qldpc_decoder *d, const bucket &b, bool first)
 {
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    if (first && !d->msg_i8) {      /* iteration 0 with coded LLRs: inputs rebuilt from the received bits, var_to_chk is not read (see qk_cn_flood FIRST) */
+        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+        if (d->msg_half)
+            hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half, true>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
+                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->d_cn_var, d->N, c);
+        else
+            hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, float, true>), grid, dim3(QK_THREADS), 0, d->stream, (const float *)d->d_a, d->d_b, b.d_list, b.n,
+                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->d_cn_var, d->N, c);
+        return;
+    }
     if (d->msg_i8) {
         if constexpr (V == QI_V && FAM == QK_FAM_MS) {
             hipLaunchKernelGGL((qi_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
@@ -476,24 +486,24 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b)
                            d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
 }
 template <int V, int FAM>
-static void launch_cn_fam(qldpc_decoder *d, const bucket &b)
+static void launch_cn_fam(qldpc_decoder *d, const bucket &b, bool first)
 {
     switch (b.cap) {
-    case 8: launch_cn_one<V, 8, FAM>(d, b); break;
-    case 12: launch_cn_one<V, 12, FAM>(d, b); break;
-    case 20: launch_cn_one<V, 20, FAM>(d, b); break;
-    case 40: launch_cn_one<V, 40, FAM>(d, b); break;
-    default: launch_cn_one<V, 0, FAM>(d, b); break;
+    case 8: launch_cn_one<V, 8, FAM>(d, b, first); break;
+    case 12: launch_cn_one<V, 12, FAM>(d, b, first); break;
+    case 20: launch_cn_one<V, 20, FAM>(d, b, first); break;
+    case 40: launch_cn_one<V, 40, FAM>(d, b, first); break;
+    default: launch_cn_one<V, 0, FAM>(d, b, first); break;
     }
 }
 template <int V>
-static void launch_cn(qldpc_decoder *d, const bucket &b)
+static void launch_cn(qldpc_decoder *d, const bucket &b, bool first)
 {
     switch (family_of(d->cfg.rule)) {
-    case QK_FAM_MS: launch_cn_fam<V, QK_FAM_MS>(d, b); break;
-    case QK_FAM_SPA: launch_cn_fam<V, QK_FAM_SPA>(d, b); break;
-    case QK_FAM_LSPA: launch_cn_fam<V, QK_FAM_LSPA>(d, b); break;
-    default: launch_cn_fam<V, QK_FAM_AMS>(d, b); break;
+    case QK_FAM_MS: launch_cn_fam<V, QK_FAM_MS>(d, b, first); break;
+    case QK_FAM_SPA: launch_cn_fam<V, QK_FAM_SPA>(d, b, first); break;
+    case QK_FAM_LSPA: launch_cn_fam<V, QK_FAM_LSPA>(d, b, first); break;
+    default: launch_cn_fam<V, QK_FAM_AMS>(d, b, first); break;
     }
 }
 
@@ -597,10 +607,10 @@ static int vn_pass(qldpc_decoder *d, float *post_out)
     return QLDPC_OK;
 }
 template <int V>
-static int cn_pass(qldpc_decoder *d)
+static int cn_pass(qldpc_decoder *d, bool first = false)
 {
     prof_scope ps(d, KS_CN, bytes_cn(d));
-    for (auto &b : d->cn_buckets) { launch_cn<V>(d, b); LAUNCHCHK(); }
+    for (auto &b : d->cn_buckets) { launch_cn<V>(d, b, first); LAUNCHCHK(); }
     return QLDPC_OK;
 }
 template <int V>
@@ -639,10 +649,13 @@ static int run_flooding(qldpc_decoder *d)
 {
     int rc;
     const int n_ite = d->cfg.n_ite;
-    if ((rc = vn_pass<V, QK_VN_FIRST>(d, nullptr))) return rc;
+    /* coded LLRs (fp32 / binary16 messages): the first check pass rebuilds its inputs itself, so _initialize_var_to_chk of
+     * iteration 0 (E rows written, E rows read back) is not run at all */
+    const bool skip_first = d->llr_coded && !d->msg_i8;
+    if (!skip_first && (rc = vn_pass<V, QK_VN_FIRST>(d, nullptr))) return rc;
     int ite = 0;
     for (; ite < n_ite; ite++) {
-        if ((rc = cn_pass<V>(d))) return rc;
+        if ((rc = cn_pass<V>(d, skip_first && ite == 0))) return rc;
         if (ite == n_ite - 1) { ite++; break; }
         if ((rc = vn_pass<V, QK_VN_NORMAL>(d, nullptr))) return rc;
         if (d->cfg.enable_syndrome) {

@@ -302,6 +302,36 @@ template <int V> __device__ __forceinline__ bool qk_frozen(const u64 *__restrict
     return any;   /* wave-uniform */
 }
 
+/*
+ * Channel LLRs of a QKD frame take three magnitudes (BS/src/main.cpp:348-362: the frame's ln((1-p)/p) at channel VNs, 23.03 at
+ * pinned VNs, 0 at punctured ones) and the sign is the received bit.  After qldpc_load_bits_* the flooding passes therefore do
+ * not read an LLR array at all (CODED = true): the received bits sit as one ballot word per VN (bit = lane, like sgn / hard),
+ * the class is a byte per VN, the magnitude and the shortening length a value per frame; Y is rebuilt in registers, the same
+ * float the array would hold.  N/8 bytes per frame and pass instead of 4 N, and the loads are scalar.
+ */
+struct qk_coded_llr {
+    const u64 *ybits;          /* [G][N][V] received bits as ballots                         */
+    const float *fmag;         /* [G*FG] |LLR| of a channel bit of each frame (padding: 1)  */
+    const int *fnch;           /* [G*FG] class-0 VNs at index >= fnch[f] are pinned (shortening) */
+    const uint8_t *vcls;       /* [N] VN class                                               */
+};
+
+
+/* Y of VN v for the V frames of this lane, rebuilt from the coded form (the float the LLR array would hold) */
+template <int V> __device__ __forceinline__ void qk_coded_y(float (&y)[V], const qk_coded_llr &c, int g, int v, int N, int lane, const float (&mg)[V], const int (&nc)[V])
+{
+    const int cls = c.vcls[v];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const bool bit = (c.ybits[((size_t)g * N + v) * V + j] >> lane) & 1ull;
+        const float m = (cls == 0) ? (v < nc[j] ? mg[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
+        y[j] = bit ? -m : m;
+    }
+}
+/* what _initialize_var_to_chk leaves in var_to_chk before the first check pass: (Y + 0) - 0, through the message type */
+__device__ __forceinline__ float qk_first_v2c(float y, const float *) { return (y + 0.0f) - 0.0f; }
+__device__ __forceinline__ float qk_first_v2c(float y, const __half *) { return __half2float(__float2half_rn((y + 0.0f) - 0.0f)); }
+
 /* ------------------------------------------------------------------ flooding: check nodes ---- */
 
 /*
@@ -313,11 +343,14 @@ template <int V> __device__ __forceinline__ bool qk_frozen(const u64 *__restrict
  * DCMAX > 0: messages stay in registers (checks in `list` have degree <= DCMAX).
  * DCMAX == 0: any degree, second pass re-reads the rows (they are L2-hot).
  */
-template <int V, int DCMAX, int FAM, typename MT>
+/* FIRST: the check pass of iteration 0 in coded-LLR mode.  var_to_chk would hold (Y + 0) - 0 on every edge, so it is not read
+ * (and the variable-node pass that would have written it is not run): the inputs are rebuilt from the coded LLRs of cn_var. */
+template <int V, int DCMAX, int FAM, typename MT, bool FIRST = false>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__ v2c, MT *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
-                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M)
+                                                          size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M,
+                                                          const int *__restrict__ cn_var = nullptr, int N = 0, qk_coded_llr coded = qk_coded_llr{})
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -346,9 +379,26 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
 #pragma unroll
         for (int k = 0; k < DCMAX; k++) slot[k] = cn_tr[b + k];
         float x[DCMAX][V];
+        if constexpr (FIRST) {
+            float mg[V];
+            int nc[V];
 #pragma unroll
-        for (int k = 0; k < DCMAX; k++)
-            if (k < deg) qk_ldm<V>(x[k], vin + (size_t)slot[k] * FG);
+            for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
+            int vid[DCMAX];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++) vid[k] = cn_var[b + k];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+                    qk_coded_y<V>(x[k], coded, g, vid[k], N, lane, mg, nc);
+#pragma unroll
+                    for (int j = 0; j < V; j++) x[k][j] = qk_first_v2c(x[k][j], vin);
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) qk_ldm<V>(x[k], vin + (size_t)slot[k] * FG);
+        }
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
@@ -376,9 +426,19 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                 }
         }
     } else {
+        float mg[V];
+        int nc[V];
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
+        }
         for (int k = 0; k < deg; k++) {
             float x[V];
-            qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
+            if constexpr (FIRST) {
+                qk_coded_y<V>(x, coded, g, cn_var[b + k], N, lane, mg, nc);
+#pragma unroll
+                for (int j = 0; j < V; j++) x[j] = qk_first_v2c(x[j], vin);
+            } else qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
 #pragma unroll
             for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], qk_prep<FAM>(x[j]), rule);
         }
@@ -387,7 +447,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
         for (int k = 0; k < deg; k++) {
             float x[V], o[V];
             const size_t off = (size_t)cn_tr[b + k] * FG;
-            qk_load<V>(x, vin + off);
+            if constexpr (FIRST) {
+                qk_coded_y<V>(x, coded, g, cn_var[b + k], N, lane, mg, nc);
+#pragma unroll
+                for (int j = 0; j < V; j++) x[j] = qk_first_v2c(x[j], vin);
+            } else qk_load<V>(x, vin + off);
 #pragma unroll
             for (int j = 0; j < V; j++) o[j] = acc[j].out(qk_prep<FAM>(x[j]), rule);
             qk_store_masked<V>(cout + off, o, frozen, any_frozen);
@@ -408,20 +472,6 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
  * check_syndrome_soft tests) and hard = !(tmp >= 0) (what decode_siho outputs).
  * One wavefront handles UN list entries with every row load issued before the first use.
  */
-/*
- * Channel LLRs of a QKD frame take three magnitudes (BS/src/main.cpp:348-362: the frame's ln((1-p)/p) at channel VNs, 23.03 at
- * pinned VNs, 0 at punctured ones) and the sign is the received bit.  After qldpc_load_bits_* the flooding passes therefore do
- * not read an LLR array at all (CODED = true): the received bits sit as one ballot word per VN (bit = lane, like sgn / hard),
- * the class is a byte per VN, the magnitude and the shortening length a value per frame; Y is rebuilt in registers, the same
- * float the array would hold.  N/8 bytes per frame and pass instead of 4 N, and the loads are scalar.
- */
-struct qk_coded_llr {
-    const u64 *ybits;          /* [G][N][V] received bits as ballots                         */
-    const float *fmag;         /* [G*FG] |LLR| of a channel bit of each frame (padding: 1)  */
-    const int *fnch;           /* [G*FG] class-0 VNs at index >= fnch[f] are pinned (shortening) */
-    const uint8_t *vcls;       /* [N] VN class                                               */
-};
-
 template <int V, int DVMAX, int UN, int MODE, typename MT, bool CODED = false>
 __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__ c2v, const float *__restrict__ llr,
                                                           MT *__restrict__ v2c, u64 *__restrict__ sgn, u64 *__restrict__ hard,
@@ -456,15 +506,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
 #pragma unroll
         for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const int cls = coded.vcls[vv[u]];
-#pragma unroll
-            for (int j = 0; j < V; j++) {
-                const bool bit = (coded.ybits[((size_t)g * N + vv[u]) * V + j] >> lane) & 1ull;
-                const float m = (cls == 0) ? (vv[u] < nc[j] ? mg[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
-                y[u][j] = bit ? -m : m;
-            }
-        }
+        for (int u = 0; u < UN; u++) qk_coded_y<V>(y[u], coded, g, vv[u], N, lane, mg, nc);
     } else {
 #pragma unroll
         for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
