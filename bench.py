@@ -305,7 +305,7 @@ def main():
             w = pmc["workload"]
             fpl = args.frames_per_lane or 1
             if (w["frames"], w["frames_per_lane"], w["N"], w["E"]) == (F, fpl, N, code.E):
-                traffic = pmc["kernels"]["qk_cn_flood<%d, 20, 0, float>" % fpl]["hbm_bytes_corrected"]
+                traffic = pmc["kernels"]["qk_cn_flood<%d, 20, 0, float, false>" % fpl]["hbm_bytes_corrected"]
                 traffic_src = "profiles/r01_d_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
         except Exception:
             pass
