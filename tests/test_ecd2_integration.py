@@ -51,7 +51,12 @@ def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
     """pristine reference daemon: both sides end with the same stream-7 key."""
     binary = need("ecd2_cascade")
     a, b = epochs(1, 4, 4001, 0.02)
-    out = run_loopback(binary, tmp_path, a, b)
+    out = run_loopback(binary, tmp_path / "try1", a, b, timeout=60)
+    if out["a_final"] is None or out["b_final"] is None:
+        # two real-time daemons of the reference talking over FIFOs: seen to stall once in ~20 runs on a loaded machine
+        # (one daemon exits early); the pristine reference is the oracle here, not the unit under test -- try once more
+        print("first attempt failed:\n" + out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:])
+        out = run_loopback(binary, tmp_path / "try2", a, b, timeout=120)
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + out["b_log"][-2000:]
     assert out["a_final"]["tag"] == 7 and out["a_final"]["nbits"] == out["b_final"]["nbits"] > 4000
     assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
