@@ -283,7 +283,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
             if ((rc = make_buckets(d, code->cn_ptr, code->layer_order + code->layer_ptr[l], code->layer_ptr[l + 1] - code->layer_ptr[l], CN_CAPS, 4, d->layer_buckets[(size_t)l]))) return rc;
     }
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
-    if ((rc = dev_alloc(d, &d->d_llr, G * d->N * FG))) return rc;
+    /* the fp32 LLR array [G][N][FG] is allocated on first use (ensure_llr): flooding decoders fed through qldpc_load_bits_* never read one */
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
         const size_t elems = d->msg_i8 ? (G * d->E * FG + 3) / 4 : (d->msg_half ? (G * d->E * FG + 1) / 2 : G * d->E * FG);      /* floats of storage */
         if (d->msg_i8 && (rc = dev_alloc(d, &d->d_llr8, G * d->N * 64))) return rc;
@@ -339,6 +339,12 @@ extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *in
     if (rc != QLDPC_OK) { qldpc_decoder_free(d); return rc; }
     *out = d;
     return QLDPC_OK;
+}
+
+static int ensure_llr(qldpc_decoder *d)
+{
+    if (d->d_llr) return QLDPC_OK;
+    return dev_alloc(d, &d->d_llr, (size_t)d->G * d->N * d->FG);
 }
 
 extern "C" int qldpc_decoder_set_stream(qldpc_decoder *d, void *s) { if (!d) return QLDPC_EINVAL; d->stream = (hipStream_t)s; return QLDPC_OK; }
@@ -906,6 +912,7 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
         d->loaded = 1; d->ran = 0;
         return QLDPC_OK;
     }
+    if ((rc = ensure_llr(d))) return rc;
     {
         prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
         dim3 grid((unsigned)((d->N + 63) / 64), (unsigned)d->G);
@@ -969,6 +976,7 @@ extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bit
         d->loaded = 1; d->ran = 0;
         return QLDPC_OK;
     }
+    if ((rc = ensure_llr(d))) return rc;
     {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
         dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
