@@ -736,7 +736,22 @@ __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask,
         u64 s[V];
 #pragma unroll
         for (int j = 0; j < V; j++) s[j] = synd ? synd[((size_t)g * M + c) * V + j] : 0ull;      /* H x must equal the target syndrome */
-        for (int k = cn_ptr[c]; k < cn_ptr[c + 1]; k++) {
+        /* six independent index loads, then six independent ballot gathers per trip (the ballot array of a group sits in L2):
+         * the one-edge-at-a-time loop was a chain of dependent loads */
+        int k = cn_ptr[c];
+        const int e = cn_ptr[c + 1];
+        for (; k + 6 <= e; k += 6) {
+            int v[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) v[t] = cn_var[k + t];
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                const u64 *p = mg + (size_t)v[t] * V;
+#pragma unroll
+                for (int j = 0; j < V; j++) s[j] ^= p[j];
+            }
+        }
+        for (; k < e; k++) {
             const u64 *p = mg + (size_t)cn_var[k] * V;
 #pragma unroll
             for (int j = 0; j < V; j++) s[j] ^= p[j];
