@@ -10,7 +10,7 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # lives in tests/: it runs the reference daemons built under oracle/_ref
 from ecd2_loopback import run_loopback  # noqa: E402
 
 binary = os.path.join(ROOT, "oracle", "_ref", sys.argv[1])

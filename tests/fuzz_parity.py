@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the HIP decoder against the CPU oracle (developer tool; run on the GPU box).
+"""Differential fuzzing of the HIP decoder against the CPU oracle (test infrastructure; run on the GPU box).
 
 Random IRA / QC-PEG codes, frame counts, QBER, update rules, schedules, engines, frames-per-lane, message widths, early exit
 on/off, syndrome form on/off.  For every case the bit-exact class (min-sum family) must agree with the oracle on hard
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ is the only place allowed to use oracle/
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import _qldpc_loader  # noqa: E402
