@@ -16,6 +16,10 @@
  * (tests/golden/kat_peg504x1008.json).  Flooding SPA is pinned by it exactly; MS/OMS/NMS and the
  * layered schedule reproduce the same decoded word but have no reference-held vector of their own;
  * LSPA / AMS rules are "parity unpinned" (restated from the published AFF3CT algorithm only).
+ * Further pins held by tests/test_oracle.py: the float layered schedule against a double-precision restatement of the
+ * reference's MATLAB recursion (ldpc_examples/.../BPSK_nrldpc_sim.m:29-69); the integer layered decoder (orc_decode_i8)
+ * against a literal restatement of its fixed-point MATLAB decoder (BPSK_nrldpc_sim_RM_FP.m:37-98, exact) and against the
+ * frame-error table the reference publishes for it (sim_results.m:8-13); the LFSR against the reference's own rnd.c.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (libqldpc.so) never links, loads or calls it.
