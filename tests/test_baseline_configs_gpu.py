@@ -93,3 +93,34 @@ def test_config4_frame_sharding_is_replica_exact(q, O, torch):
         parts.append(decode(q, torch, q.Decoder(code, 6554, 30, rule="NMS", rule_param=0.75, n_frames=hi - lo), llr[lo:hi]))
     assert (np.concatenate([p[0] for p in parts]) == whole[0]).all()
     assert (np.concatenate([p[1] for p in parts]) == whole[1]).all()
+
+
+@pytest.mark.parametrize("F", [4096, 32768])
+def test_config2_and_config4_shard_at_full_size_properties(q, torch, F):
+    """BASELINE configs 2 (4 096 frames) and 4 (its per-GPU shard of 32 768 frames, 63 GB of decoder state) at full size, through
+    size-independent properties: encode -> BSC -> decode round trip (every word equals Alice's), H x = 0 for every decoded
+    word computed on the device, linearity (the XOR of two decoded words is a codeword), success flags, and iteration counts in
+    the band the small-sample parity tests see.  No oracle at this size: those tests cover the arithmetic."""
+    import bench
+    dev = torch.device("cuda", 0)
+    code = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
+    enc = q.Encoder(code, "IRA")
+    K, N = enc.K, code.N
+    cw, rx = bench.make_frames(q, torch, code, enc, F, 0.02, 4242, dev)
+    assert (cw != rx).any(dim=1).all()                                    # every frame really carries channel errors
+    mag = torch.full((F,), q.bsc_llr(0.02), dtype=torch.float32, device=dev)
+    cls = torch.zeros(N, dtype=torch.uint8, device=dev)
+    cls[K:] = q.VN_PINNED
+    dec = q.Decoder(code, K, 50, rule="NMS", rule_param=0.75, n_frames=F)
+    dec.load_bits(rx, mag, cls)
+    dec.run()
+    out = dec.fetch_packed()
+    it, ok = dec.fetch_status()
+    assert bool((ok == 1).all()) and bool((out == cw).all())
+    assert 8 <= int(it.min()) and int(it.max()) <= 20 and 10.5 < float(it.float().mean()) < 12.5
+    assert not bool(dec.syndrome_of(out).any())                           # H x = 0 on the device, all frames
+    mixed = out[: F // 2] ^ out[F // 2:]
+    assert not bool(dec.syndrome_of(mixed.contiguous()).any())            # linearity
+    assert bool(dec.syndrome_of(rx).any(dim=1).all())                     # while Bob's raw words are not codewords
+    del dec
+    torch.cuda.empty_cache()
