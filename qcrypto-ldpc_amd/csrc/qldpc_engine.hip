@@ -976,6 +976,15 @@ extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bit
         d->loaded = 1; d->ran = 0;
         return QLDPC_OK;
     }
+    if (d->msg_i8) {
+        /* 8-bit variant: straight into the quantised array, no fp32 LLRs in between */
+        prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N) * n_frames);
+        dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+        hipLaunchKernelGGL(qi_load_bits, grid, dim3(QK_THREADS), 0, d->stream, d_bits, d_llr_mag, d_vn_class, d->d_llr8, d->N, W, n_frames, d_n_channel, d->quant_scale);
+        LAUNCHCHK();
+        d->loaded = 1; d->ran = 0;
+        return QLDPC_OK;
+    }
     if ((rc = ensure_llr(d))) return rc;
     {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);

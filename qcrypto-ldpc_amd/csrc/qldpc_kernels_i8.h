@@ -414,6 +414,49 @@ __global__ __launch_bounds__(256) void qi_post_to_f32(const uint32_t *__restrict
     }
 }
 
+/*
+ * QKD frame formation straight into the quantised form (qk_load_bits followed by qi_quant_llr, without the fp32 array in
+ * between): packed sifted-key words + per-frame |LLR| -> llr8[G][N][256], Yq = +-quant(|LLR|) at channel VNs, +-quant(23.03) at
+ * pinned VNs (and at channel VNs past the frame's shortening length), 0 at punctured VNs; padding frames get quant(1).
+ */
+__global__ __launch_bounds__(QK_THREADS) void qi_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag,
+                                                           const uint8_t *__restrict__ vn_class, uint32_t *__restrict__ llr8,
+                                                           int N, int W, int n_frames, const int *__restrict__ n_channel, float scale)
+{
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int qm[QI_V], nch[QI_V];
+    bool live[QI_V];
+    const int qpin = qi_quant1(23.025850929840455f, scale), qpad = qi_quant1(1.0f, scale);
+#pragma unroll
+    for (int j = 0; j < QI_V; j++) {
+        const int f = g * QI_FG + lane * QI_V + j;
+        live[j] = f < n_frames;
+        qm[j] = live[j] ? qi_quant1(llr_mag[f], scale) : 0;
+        nch[j] = (n_channel && live[j]) ? n_channel[f] : N;
+    }
+    for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
+        uint32_t word[QI_V];
+#pragma unroll
+        for (int j = 0; j < QI_V; j++) word[j] = live[j] ? bits[(size_t)(g * QI_FG + lane * QI_V + j) * W + w] : 0u;
+        for (int b = 0; b < 32; b++) {
+            const int v = w * 32 + b;
+            if (v >= N) break;
+            const int cls = vn_class ? vn_class[v] : 0;
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < QI_V; j++) {
+                const bool y = (word[j] >> (31 - b)) & 1u;
+                const int m = (cls == 0) ? (v < nch[j] ? qm[j] : qpin) : (cls == 1 ? qpin : 0);
+                const int q = live[j] ? (y ? -m : m) : qpad;
+                o |= (uint32_t)(q & 0xff) << (8 * j);
+            }
+            llr8[((size_t)g * N + v) * 64 + lane] = o;
+        }
+    }
+}
+
 /* channel LLRs [G][N][256] f32 -> [G][N][256] int8, four frames of a lane per dword */
 __global__ __launch_bounds__(256) void qi_quant_llr(const float *__restrict__ llr, uint32_t *__restrict__ llr8, size_t n_dwords, float scale)
 {
