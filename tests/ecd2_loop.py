@@ -28,6 +28,8 @@ for trial in range(runs):
     d = pathlib.Path(tempfile.mkdtemp())
     out = run_loopback(binary, d, a, b, env_extra=env, blocks=[2] * 8, timeout=40)
     missing = [hex(k) for k, v in out["finals"].items() if v[0] is None or v[1] is None]
+    missing += ["%x differs" % k for k, v in out["finals"].items() if v[0] is not None and v[1] is not None and
+                (v[0]["nbits"] != v[1]["nbits"] or not (v[0]["words"] == v[1]["words"]).all())]
     if missing:
         bad += 1
         first = [l for l in out["b_log"].splitlines() if "qber_processReceivedQberEstBits" in l][-1]
