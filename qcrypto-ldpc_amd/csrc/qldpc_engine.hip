@@ -549,6 +549,9 @@ static void launch_layer(qldpc_decoder *d, const bucket &b)
     }
 }
 
+/* the in-between variable-node passes only need to leave ballots when the syndrome test reads them; _compute_post always does */
+static int want_ballots(const qldpc_decoder *d, int mode) { return (mode == QK_VN_POST || d->cfg.enable_syndrome) ? 1 : 0; }
+
 template <int V, int CAP, int UNX, int MODE, typename MT>
 static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
 {
@@ -556,11 +559,11 @@ static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
     if (d->llr_coded) {
         qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
         hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, true>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, (const float *)nullptr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c);
+                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c, want_ballots(d, MODE));
         return;
     }
     hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, false>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{});
+                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{}, want_ballots(d, MODE));
 }
 template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
@@ -572,10 +575,10 @@ static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
             if (d->llr_coded) {
                 qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
                 hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, (const uint32_t *)nullptr, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale);
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale, want_ballots(d, MODE));
             } else
                 hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f);
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f, want_ballots(d, MODE));
         }
         return;
     }

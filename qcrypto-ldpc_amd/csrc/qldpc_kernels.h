@@ -478,7 +478,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride,
-                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{})
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, int want_ballots = 1)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
      * showed up in the profile: +16 % on the 8-bit VN pass, where V = 4) */
     u64 mine = 0;
     u64 *dst = sgn;
+    if (want_ballots) {      /* wave-uniform: without the syndrome test nobody reads the ballots of the in-between passes, only those of _compute_post */
 #pragma unroll
     for (int u = 0; u < UN; u++) {
 #pragma unroll
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
         }
     }
     if (lane < 2 * UN * V) *dst = mine;      /* a repeated tail entry writes the same value to the same address */
+    }
 #pragma unroll
     for (int u = 0; u < UN; u++) {
         if constexpr (MODE == QK_VN_POST) {

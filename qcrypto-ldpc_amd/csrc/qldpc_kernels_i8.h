@@ -178,7 +178,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride /* dwords */,
-                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f)
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f, int want_ballots = 1)
 {
     const int g = blockIdx.y;
     if (MODE != QK_VN_POST && qk_group_done<QI_V>(done, g)) return;
@@ -275,12 +275,14 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
     for (int u = 0; u < UN; u++) {
         const short t[QI_V] = {tl[u].x, tl[u].y, th[u].x, th[u].y};
         const size_t b0 = ((size_t)g * N + vv[u]) * QI_V;
+        if (want_ballots) {      /* wave-uniform; see qk_vn_flood */
 #pragma unroll
-        for (int j = 0; j < QI_V; j++) {
-            u64 s = __ballot(t[j] < 0);
-            const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * QI_V + j];
-            if (dm) s = (s & ~dm) | (sgn[b0 + j] & dm);       /* converged frames keep the ballots they converged with */
-            if (lane == u * QI_V + j) { mine = s; dst = sgn + b0 + j; }
+            for (int j = 0; j < QI_V; j++) {
+                u64 s = __ballot(t[j] < 0);
+                const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * QI_V + j];
+                if (dm) s = (s & ~dm) | (sgn[b0 + j] & dm);       /* converged frames keep the ballots they converged with */
+                if (lane == u * QI_V + j) { mine = s; dst = sgn + b0 + j; }
+            }
         }
         if constexpr (MODE == QK_VN_POST) {
             if (post_out) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             }
         }
     }
-    if (lane < UN * QI_V) { *dst = mine; if (hard) hard[dst - sgn] = mine; }
+    if (want_ballots && lane < UN * QI_V) { *dst = mine; if (hard) hard[dst - sgn] = mine; }
 }
 
 /* ------------------------------------------------------------------ horizontal layered ------- */
