@@ -175,7 +175,8 @@ static int ldpc_fallBackToCascade(ProcessBlock *pb, PROCESSOR_ROLE role)
         pb->leakageBits += spent;
         return errorCode;
     }
-    for (i = 0; i < LDPC_FALLBACK_SLOTS && g_fallback[i].used; i++) ;
+    for (i = 0; i < LDPC_FALLBACK_SLOTS; i++)      /* a free slot, or one whose block is gone (dropped before its parity list arrived) */
+        if (!g_fallback[i].used || !pBlkMgmt_getProcessBlk(g_fallback[i].epoch)) break;
     if (i == LDPC_FALLBACK_SLOTS) return LDPC_ERR_ENGINE;
     g_fallback[i].epoch = pb->startEpoch; g_fallback[i].spentBits = spent; g_fallback[i].used = 1;
     cascade_calck0k1(pb);
