@@ -472,8 +472,12 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b, bool first)
     }
     if (d->msg_i8) {
         if constexpr (V == QI_V && FAM == QK_FAM_MS) {
-            hipLaunchKernelGGL((qi_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
-                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
+            if (first)
+                hipLaunchKernelGGL((qi_cn_flood<CAP, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
+                                   d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M, d->d_llr8, d->d_cn_var, d->N);
+            else
+                hipLaunchKernelGGL((qi_cn_flood<CAP, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
+                                   d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M, (const uint32_t *)nullptr, (const int *)nullptr, 0);
         }
         return;
     }
@@ -660,7 +664,7 @@ static int run_flooding(qldpc_decoder *d)
     const int n_ite = d->cfg.n_ite;
     /* coded LLRs (fp32 / binary16 messages): the first check pass rebuilds its inputs itself, so _initialize_var_to_chk of
      * iteration 0 (E rows written, E rows read back) is not run at all */
-    const bool skip_first = d->llr_coded && !d->msg_i8;
+    const bool skip_first = d->msg_i8 ? !d->llr_coded : (d->llr_coded != 0);      /* 8-bit: the first check pass reads llr8 itself */
     if (!skip_first && (rc = vn_pass<V, QK_VN_FIRST>(d, nullptr))) return rc;
     int ite = 0;
     for (; ite < n_ite; ite++) {

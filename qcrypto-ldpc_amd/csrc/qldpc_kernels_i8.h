@@ -104,12 +104,15 @@ struct qi_acc {
 
 /* ------------------------------------------------------------------ check nodes -------------- */
 
-template <int DCMAX>
+/* FIRST: the check pass of iteration 0 reads the quantised channel LLRs of its VNs (what the first variable-node pass would
+ * have copied into var_to_chk: |Yq| <= 127 needs no clamp), so that pass is not run */
+template <int DCMAX, bool FIRST = false>
 __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__restrict__ v2c, uint32_t *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                                           size_t group_stride /* dwords */, const u64 *__restrict__ done, qi_rule rule,
-                                                          const u64 *__restrict__ synd, int M)
+                                                          const u64 *__restrict__ synd, int M,
+                                                          const uint32_t *__restrict__ llr8 = nullptr, const int *__restrict__ cn_var = nullptr, int N = 0)
 {
     const int g = blockIdx.y;
     if (qk_group_done<QI_V>(done, g)) return;
@@ -136,9 +139,18 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
 #pragma unroll
         for (int k = 0; k < DCMAX; k++) slot[k] = cn_tr[b + k];
         uint32_t w[DCMAX];
+        if constexpr (FIRST) {
+            int vid[DCMAX];
 #pragma unroll
-        for (int k = 0; k < DCMAX; k++)
-            if (k < deg) w[k] = qi_ldm(vin + (size_t)slot[k] * 64);
+            for (int k = 0; k < DCMAX; k++) vid[k] = cn_var[b + k];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) w[k] = llr8[((size_t)g * N + vid[k]) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) w[k] = qi_ldm(vin + (size_t)slot[k] * 64);
+        }
         qi_s2 xl[DCMAX], xh[DCMAX];
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
@@ -150,14 +162,14 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
     } else {
         for (int k = 0; k < deg; k++) {
             qi_s2 xl, xh;
-            qi_unpack(vin[(size_t)cn_tr[b + k] * 64], xl, xh);
+            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : vin[(size_t)cn_tr[b + k] * 64], xl, xh);
             lo.in(xl); hi.in(xh);
         }
         lo.finish(rule); hi.finish(rule);
         for (int k = 0; k < deg; k++) {
             const size_t off = (size_t)cn_tr[b + k] * 64;
             qi_s2 xl, xh;
-            qi_unpack(vin[off], xl, xh);
+            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : vin[off], xl, xh);
             cout[off] = qi_pack(lo.out(xl), hi.out(xh));
         }
     }
