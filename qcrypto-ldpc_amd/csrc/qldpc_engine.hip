@@ -76,6 +76,7 @@ struct qldpc_decoder {
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
     /* coded channel LLRs (flooding, fp32 / binary16 messages, after qldpc_load_bits_*): no LLR array is read, see qk_coded_llr */
     u64 *d_ybits; float *d_fmag; int *d_fnch; uint8_t *d_vcls; int llr_coded;
+    int post_closes_run;             /* set around the _compute_post that ends an early-exit run (not for posterior read-back) */
     int packed_h16;                  /* binary16 variant: use the packed check-node kernel when V == 2 (QLDPC_PACKED_H16=0 turns it off) */
     int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */
     uint32_t *d_llr8;                /* [G][N][256] quantised channel LLRs, four frames of a lane per dword */
@@ -554,7 +555,11 @@ static void launch_layer(qldpc_decoder *d, const bucket &b)
 }
 
 /* the in-between variable-node passes only need to leave ballots when the syndrome test reads them; _compute_post always does */
-static int want_ballots(const qldpc_decoder *d, int mode) { return (mode == QK_VN_POST || d->cfg.enable_syndrome) ? 1 : 0; }
+static int want_ballots(const qldpc_decoder *d, int mode)
+{
+    if (mode == QK_VN_POST) return 1 | (d->post_closes_run ? 2 : 0);      /* bit 1: skip groups that converged as a whole (their ballots are final) */
+    return d->cfg.enable_syndrome ? 1 : 0;
+}
 
 template <int V, int CAP, int UNX, int MODE, typename MT>
 static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
@@ -683,8 +688,10 @@ static int run_flooding(qldpc_decoder *d)
     }
     d->last_iters = ite;
     /* final _compute_post for every frame (frozen frames recompute the posterior they stopped at) */
-    if ((rc = vn_pass<V, QK_VN_POST>(d, nullptr))) return rc;
-    return QLDPC_OK;
+    d->post_closes_run = d->cfg.enable_syndrome ? 1 : 0;
+    rc = vn_pass<V, QK_VN_POST>(d, nullptr);
+    d->post_closes_run = 0;
+    return rc;
 }
 
 static int bx_of(const qldpc_decoder *d) { return std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, d->G))); }

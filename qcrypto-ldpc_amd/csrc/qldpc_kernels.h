@@ -482,7 +482,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
-    if (MODE != QK_VN_POST && qk_group_done<V>(done, g)) return;
+    /* want_ballots bit 1: this _compute_post closes an early-exit run -- a group whose frames have all converged already holds its
+     * final (frozen) ballots and is skipped; without it (posterior read-back) every group is recomputed */
+    if ((MODE != QK_VN_POST || (want_ballots & 2)) && qk_group_done<V>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const MT *cin = c2v + (size_t)g * group_stride + lane * V;

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
                                                           const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f, int want_ballots = 1)
 {
     const int g = blockIdx.y;
-    if (MODE != QK_VN_POST && qk_group_done<QI_V>(done, g)) return;
+    if ((MODE != QK_VN_POST || (want_ballots & 2)) && qk_group_done<QI_V>(done, g)) return;      /* bit 1: see qk_vn_flood */
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t *cin = c2v + (size_t)g * group_stride + lane;
