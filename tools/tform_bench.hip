@@ -150,17 +150,222 @@ __global__ __launch_bounds__(256) void b2_vn(const float* __restrict__ c2v, cons
     T[((size_t)g * N + v) * 64 + lane] = ldnt(llr + ((size_t)g * N + v) * 64 + lane) + sum;
 }
 
+
+// C: compressed check state.  The CN pass gathers v2c rows as in A but writes, per check, the two candidate magnitudes
+// (cst1 = rule(min2), cst2 = rule(min1)) as one [64][2] row of 512 B plus two ballot words per edge (sign of the outgoing
+// message, "this edge holds min1") -- 16 B per edge instead of a 256-B c2v row.  The VN pass rebuilds c2v = +-(ismin ? cst1 : cst2)
+// (the select AFF3CT's compute_chk_node_out makes) from the state rows of its checks (gathered: 6.7 MB per group, re-used dc
+// times, so they should come from L2 / Infinity Cache) and streams v2c out.  HBM rows per iteration: 2E + 2*2M + E/8.
+typedef unsigned long long u64;
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <bool NT_S>
+__global__ __launch_bounds__(256) void c_cn(const float* __restrict__ v2c, f2* __restrict__ S, u64* __restrict__ bits, const int* __restrict__ slot, int M, size_t E)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bpg = (M + 3) / 4;
+    const int g = blockIdx.x / bpg, c = (blockIdx.x % bpg) * 4 + wave;
+    if (c >= M) return;
+    int s[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) s[k] = slot[c * DC + k];
+    const float* in = v2c + (size_t)g * E * 64 + lane;
+    float v[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) v[k] = ldnt(in + (size_t)s[k] * 64);
+    float m1 = 3e38f, m2 = 3e38f; unsigned sg = 0;
+#pragma unroll
+    for (int k = 0; k < DC; k++) { float a = fabsf(v[k]); sg ^= __float_as_uint(v[k]) & 0x80000000u; float t = fminf(a, m2); m2 = fmaxf(t, m1); m1 = fminf(t, m1); }
+    f2 st; st.x = m2 * 0.75f; st.y = m1 * 0.75f;
+    f2* sp = S + ((size_t)g * M + c) * 64 + lane;
+    if (NT_S) __builtin_nontemporal_store(st, sp); else *sp = st;
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < DC; k++) {
+        const u64 bs = __ballot(((sg ^ __float_as_uint(v[k])) >> 31) != 0);
+        const u64 bm = __ballot(fabsf(v[k]) == m1);
+        if (lane == 2 * k) mine = bs;
+        if (lane == 2 * k + 1) mine = bm;
+    }
+    if (lane < 2 * DC) bits[((size_t)g * E + (size_t)c * DC) * 2 + lane] = mine;
+}
+// VN pass of form C over VNs [v_lo, v_hi), all of degree <= DVMAX; cnslot[s] = CN-major edge index of VN-major slot s (check = e / DC)
+__device__ __forceinline__ float c_sel(u64 bm, u64 bs, float a, float b)
+{
+    float mag, sg;
+    asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(mag) : "v"(b), "v"(a), "s"(bm));
+    asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(sg) : "v"(__uint_as_float(0x80000000u)), "s"(bs));
+    return __uint_as_float(__float_as_uint(mag) | __float_as_uint(sg));
+}
+template <int DVMAX, int UN, bool ASM>
+__global__ __launch_bounds__(256) void c_vn(const f2* __restrict__ S, const u64* __restrict__ bits, const float* __restrict__ llr, float* __restrict__ v2c,
+                                            const int* __restrict__ vptr, const int* __restrict__ cnslot, int M, int N, size_t E, int v_lo, int v_hi)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nv = v_hi - v_lo;
+    const int bpg = (nv + 4 * UN - 1) / (4 * UN);
+    const int g = blockIdx.x / bpg;
+    const int i0 = ((blockIdx.x % bpg) * 4 + wave) * UN;
+    if (i0 >= nv) return;
+    const f2* sg = S + (size_t)g * M * 64 + lane;
+    const u64* bg = bits + (size_t)g * E * 2;
+    int vv[UN], s0[UN], d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { vv[u] = v_lo + min(i0 + u, nv - 1); s0[u] = vptr[vv[u]]; d[u] = vptr[vv[u] + 1] - s0[u]; }
+    int e[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];      /* padded array: reads past d stay in bounds */
+    }
+    f2 st[UN][DVMAX]; u64 bs[UN][DVMAX], bm[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) { st[u][k] = sg[(size_t)(e[u][k] / DC) * 64]; bs[u][k] = bg[(size_t)e[u][k] * 2]; bm[u][k] = bg[(size_t)e[u][k] * 2 + 1]; }
+    }
+    float y[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) y[u] = ldnt(llr + ((size_t)g * N + vv[u]) * 64 + lane);
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        float m[DVMAX]; float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) {
+                if (ASM) m[k] = c_sel(bm[u][k], bs[u][k], st[u][k].x, st[u][k].y);
+                else {
+                    const float mag = ((bm[u][k] >> lane) & 1ull) ? st[u][k].x : st[u][k].y;
+                    m[k] = __uint_as_float(__float_as_uint(mag) | ((unsigned)((bs[u][k] >> lane) & 1ull) << 31));
+                }
+                sum += m[k];
+            }
+        const float t = y[u] + sum;
+        float* out = v2c + ((size_t)g * E + s0[u]) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) stnt(out + (size_t)k * 64, t - m[k]);
+    }
+}
+
+// C2: as C, but the per-edge ballots shrink to what the variable node cannot know itself: the check keeps {cst1, cst2}[64], the
+// argmin edge position per frame (one byte per lane) and its sign product (one ballot word) in ONE 640-byte record; the variable
+// node keeps the sign ballots of the messages it sent (VN-major, contiguous, 8 B per edge).  sign(c2v) = signprod ^ sign(v2c sent),
+// |c2v| = (argmin == position of this edge in the check) ? cst1 : cst2 -- on a tie min2 == min1, so any argmin gives the same float.
+// XCD: 1 = group g is processed by XCD g % 8 only (blocks are dealt round-robin to the 8 XCDs), so its state table is gathered
+// through ONE 4-MiB L2 instead of being pulled into all eight.
+struct c2_rec { f2 cst[64]; unsigned char am[64]; u64 sp; u64 pad[7]; };
+template <bool XCD> __device__ __forceinline__ void c2_map(int bpg, int G, int& g, int& blk)
+{
+    if (XCD) { const int x = blockIdx.x & 7, j = blockIdx.x >> 3; g = x + 8 * (j / bpg); blk = j % bpg; }
+    else { g = blockIdx.x / bpg; blk = blockIdx.x % bpg; }
+    (void)G;
+}
+template <bool XCD>
+__global__ __launch_bounds__(256) void c2_cn(const float* __restrict__ v2c, c2_rec* __restrict__ S, const int* __restrict__ slot, int M, size_t E, int G)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bpg = (M + 3) / 4;
+    int g, blk; c2_map<XCD>(bpg, G, g, blk);
+    const int c = blk * 4 + wave;
+    if (c >= M) return;
+    int s[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) s[k] = slot[c * DC + k];
+    const float* in = v2c + (size_t)g * E * 64 + lane;
+    float v[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) v[k] = ldnt(in + (size_t)s[k] * 64);
+    float m1 = 3e38f, m2 = 3e38f; unsigned sg = 0; int am = 0;
+#pragma unroll
+    for (int k = 0; k < DC; k++) { float a = fabsf(v[k]); sg ^= __float_as_uint(v[k]); if (a < m1) am = k; float t = fminf(a, m2); m2 = fmaxf(t, m1); m1 = fminf(t, m1); }
+    c2_rec* r = S + (size_t)g * M + c;
+    f2 st; st.x = m2 * 0.75f; st.y = m1 * 0.75f;
+    r->cst[lane] = st;
+    r->am[lane] = (unsigned char)am;
+    const u64 sp = __ballot((sg >> 31) != 0);
+    if (lane == 0) r->sp = sp;
+}
+template <int DVMAX, int UN, bool XCD>
+__global__ __launch_bounds__(256) void c2_vn(const c2_rec* __restrict__ S, u64* __restrict__ vsgn, const float* __restrict__ llr, float* __restrict__ v2c,
+                                             const int* __restrict__ vptr, const int* __restrict__ cnslot, int M, int N, size_t E, int v_lo, int v_hi, int G)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nv = v_hi - v_lo;
+    const int bpg = (nv + 4 * UN - 1) / (4 * UN);
+    int g, blk; c2_map<XCD>(bpg, G, g, blk);
+    const int i0 = (blk * 4 + wave) * UN;
+    if (i0 >= nv) return;
+    const c2_rec* sg = S + (size_t)g * M;
+    u64* og = vsgn + (size_t)g * E;
+    int vv[UN], s0[UN], d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { vv[u] = v_lo + min(i0 + u, nv - 1); s0[u] = vptr[vv[u]]; d[u] = vptr[vv[u] + 1] - s0[u]; }
+    int e[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];
+    }
+    f2 st[UN][DVMAX]; u64 sp[UN][DVMAX], own[UN][DVMAX]; int am[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) {
+                const c2_rec* r = sg + e[u][k] / DC;
+                st[u][k] = r->cst[lane]; am[u][k] = r->am[lane]; sp[u][k] = r->sp; own[u][k] = og[s0[u] + k];
+            }
+    }
+    float y[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) y[u] = ldnt(llr + ((size_t)g * N + vv[u]) * 64 + lane);
+    u64 mine = 0; u64* dst = og;
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        float m[DVMAX]; float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) {
+                const float mag = (am[u][k] == e[u][k] % DC) ? st[u][k].x : st[u][k].y;
+                float sgn;
+                asm volatile("v_cndmask_b32 %0, 0, %1, %2" : "=v"(sgn) : "v"(__uint_as_float(0x80000000u)), "s"(sp[u][k] ^ own[u][k]));
+                m[k] = __uint_as_float(__float_as_uint(mag) | __float_as_uint(sgn));
+                sum += m[k];
+            }
+        const float t = y[u] + sum;
+        float* out = v2c + ((size_t)g * E + s0[u]) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++)
+            if (k < d[u]) {
+                const float o = t - m[k];
+                stnt(out + (size_t)k * 64, o);
+                const u64 b = __ballot((__float_as_uint(o) >> 31) != 0);
+                if (lane == u * DVMAX + k) { mine = b; dst = og + s0[u] + k; }
+            }
+    }
+    if (UN * DVMAX <= 64 && dst != og) *dst = mine;
+}
+
 int main(int argc, char** argv)
 {
     const int M = 13107, K = 52429, N = M + K, G = argc > 1 ? atoi(argv[1]) : 64;
     const size_t E = (size_t)M * DC;
     std::mt19937 rng(7);
     std::vector<int> var(E);
-    for (int c = 0; c < M; c++) {
-        int* r = &var[(size_t)c * DC];
-        for (int k = 0; k < DC - 2;) { int v = rng() % K; bool dup = false; for (int j = 0; j < k; j++) dup |= r[j] == v; if (!dup) r[k++] = v; }
-        std::sort(r, r + DC - 2);
-        r[DC - 2] = K + (c == 0 ? M - 1 : c - 1); r[DC - 1] = K + c;      // accumulator chain (wrap only to keep dc fixed)
+    {   // config-2 profile: 6553 information VNs of degree 11, the rest degree 3 (one of degree 4), configuration-model matching, VNs 0..K-1
+        std::vector<int> sock; sock.reserve((size_t)M * (DC - 2));
+        const int n11 = 6553;
+        for (int v = 0; v < K; v++) { int dv = v < n11 ? 11 : 3; for (int j = 0; j < dv; j++) sock.push_back(v); }
+        while (sock.size() < (size_t)M * (DC - 2)) sock.push_back(n11 + (int)sock.size() % 1000);
+        sock.resize((size_t)M * (DC - 2));
+        std::shuffle(sock.begin(), sock.end(), rng);
+        for (int c = 0; c < M; c++) {
+            int* r = &var[(size_t)c * DC];
+            for (int k = 0; k < DC - 2; k++) r[k] = sock[(size_t)c * (DC - 2) + k];
+            std::sort(r, r + DC - 2);
+            r[DC - 2] = K + (c == 0 ? M - 1 : c - 1); r[DC - 1] = K + c;
+        }
     }
     // VN-major slots
     std::vector<int> vptr(N + 1, 0);
@@ -170,12 +375,13 @@ int main(int argc, char** argv)
     for (size_t e = 0; e < E; e++) { int s = fill[var[e]]++; slot[e] = s; cnslot[s] = (int)e; }
     printf("M %d N %d E %zu groups %d (frames %d) max dv %d\n", M, N, E, G, G * 64, maxd);
     if (maxd > 16) { printf("dv > 16: regenerate\n"); return 1; }
+    { int bad = 0; for (int v = 6553; v < N; v++) bad += (vptr[v + 1] - vptr[v]) > 4; for (int v = 0; v < 6553; v++) bad += (vptr[v + 1] - vptr[v]) > 12; if (bad) { printf("degree profile off: %d\n", bad); return 1; } }
 
     const size_t msg = (size_t)G * E * 64 * 4, nb = (size_t)G * N * 64 * 4;
     float *v2c, *c2v, *llr, *T; int *d_var, *d_slot, *d_vptr, *d_cnslot;
     CK(hipMalloc(&v2c, msg)); CK(hipMalloc(&c2v, msg)); CK(hipMalloc(&llr, nb)); CK(hipMalloc(&T, nb));
     CK(hipMemset(v2c, 0x3c, msg)); CK(hipMemset(c2v, 0x3c, msg)); CK(hipMemset(llr, 0x3c, nb)); CK(hipMemset(T, 0x3c, nb));
-    CK(hipMalloc(&d_var, E * 4)); CK(hipMalloc(&d_slot, E * 4)); CK(hipMalloc(&d_vptr, (N + 1) * 4)); CK(hipMalloc(&d_cnslot, E * 4));
+    CK(hipMalloc(&d_var, E * 4)); CK(hipMalloc(&d_slot, E * 4)); CK(hipMalloc(&d_vptr, (N + 1) * 4)); CK(hipMalloc(&d_cnslot, (E + 64) * 4)); CK(hipMemset(d_cnslot, 0, (E + 64) * 4));
     CK(hipMemcpy(d_var, var.data(), E * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_slot, slot.data(), E * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_vptr, vptr.data(), (N + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_cnslot, cnslot.data(), E * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -194,6 +400,53 @@ int main(int argc, char** argv)
     float bvn = timeit("B vn  gather, write T  (E+2N)", 1.0 * E + 2.0 * N, [&] { b_vn<<<gvn, 256>>>(c2v, llr, T, d_vptr, d_cnslot, N, E); });
     float b2cn = timeit("B' cn gather c2v+T, scatter (2E+N..3E)", 2.0 * E + N, [&] { b2_cn<<<gcn, 256>>>(c2v, T, d_slot, d_var, M, N, E); });
     float b2vn = timeit("B' vn contiguous, write T  (E+2N)", 1.0 * E + 2.0 * N, [&] { b2_vn<<<gvn, 256>>>(c2v, llr, T, d_vptr, N, E); });
+
+    {
+        f2* S; u64* bits;
+        CK(hipMalloc(&S, (size_t)G * M * 64 * 8)); CK(hipMalloc(&bits, (size_t)G * E * 16));
+        CK(hipMemset(S, 0x3c, (size_t)G * M * 64 * 8)); CK(hipMemset(bits, 0x5a, (size_t)G * E * 16));
+        const double crows_cn = 1.0 * E + 2.0 * M + E / 16.0, crows_vn = 1.0 * E + 2.0 * M + E / 16.0 + N;
+        float ccn = timeit("C cn  gather, write state (E+2M+E/16)", crows_cn, [&] { c_cn<false><<<gcn, 256>>>(v2c, S, bits, d_slot, M, E); });
+        float ccn2 = timeit("C cn  same, nt state stores", crows_cn, [&] { c_cn<true><<<gcn, 256>>>(v2c, S, bits, d_slot, M, E); });
+        const int n11 = 6553;
+        auto cvn = [&](auto hi, auto lo, int un_hi, int un_lo) {      /* hi = degree-11 VNs [0, n11), lo = the rest (degree <= 4) */
+            hi(G * ((n11 + 4 * un_hi - 1) / (4 * un_hi)));
+            lo(G * ((N - n11 + 4 * un_lo - 1) / (4 * un_lo)));
+        };
+        float cvn1 = timeit("C vn  UN 1/4 state gather, stream v2c", crows_vn, [&] { cvn(
+            [&](int gr) { c_vn<12, 1, false><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, 0, n11); },
+            [&](int gr) { c_vn<4, 4, false><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, n11, N); }, 1, 4); });
+        float cvn2 = timeit("C vn  UN 2/4, cndmask by SGPR mask", crows_vn, [&] { cvn(
+            [&](int gr) { c_vn<12, 2, true><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, 0, n11); },
+            [&](int gr) { c_vn<4, 4, true><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, n11, N); }, 2, 4); });
+        float cvn4 = timeit("C vn  UN 1/2, cndmask by SGPR mask", crows_vn, [&] { cvn(
+            [&](int gr) { c_vn<12, 1, true><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, 0, n11); },
+            [&](int gr) { c_vn<4, 2, true><<<gr, 256>>>(S, bits, llr, v2c, d_vptr, d_cnslot, M, N, E, n11, N); }, 1, 2); });
+        const float cbest = std::min(ccn, ccn2) + std::min(cvn1, std::min(cvn2, cvn4));
+        printf("iteration: C %.3f ms (%.1f %% vs A %.3f ms)\n", cbest, 100.0 * cbest / (acn + avn) - 100.0, acn + avn);
+    }
+
+    {
+        c2_rec* S2; u64* vs;
+        CK(hipMalloc(&S2, (size_t)G * M * sizeof(c2_rec))); CK(hipMalloc(&vs, (size_t)G * E * 8));
+        CK(hipMemset(S2, 0x3c, (size_t)G * M * sizeof(c2_rec))); CK(hipMemset(vs, 0x5a, (size_t)G * E * 8));
+        const int n11 = 6553;
+        const double r_cn = 1.0 * E + 2.5 * M, r_vn = 1.0 * E + 2.5 * M + E / 16.0 + N;
+        float best = 1e9f;
+        for (int x = 0; x < 2; x++) {
+            if (x && (G % 8)) break;
+            float t1 = x ? timeit("C2 cn XCD-exclusive groups", r_cn, [&] { c2_cn<true><<<gcn, 256>>>(v2c, S2, d_slot, M, E, G); })
+                         : timeit("C2 cn group-major", r_cn, [&] { c2_cn<false><<<gcn, 256>>>(v2c, S2, d_slot, M, E, G); });
+            float t2 = x ? timeit("C2 vn XCD-exclusive groups, UN 2/4", r_vn, [&] {
+                               c2_vn<12, 2, true><<<G * ((n11 + 7) / 8), 256>>>(S2, vs, llr, v2c, d_vptr, d_cnslot, M, N, E, 0, n11, G);
+                               c2_vn<4, 4, true><<<G * ((N - n11 + 15) / 16), 256>>>(S2, vs, llr, v2c, d_vptr, d_cnslot, M, N, E, n11, N, G); })
+                         : timeit("C2 vn group-major, UN 2/4", r_vn, [&] {
+                               c2_vn<12, 2, false><<<G * ((n11 + 7) / 8), 256>>>(S2, vs, llr, v2c, d_vptr, d_cnslot, M, N, E, 0, n11, G);
+                               c2_vn<4, 4, false><<<G * ((N - n11 + 15) / 16), 256>>>(S2, vs, llr, v2c, d_vptr, d_cnslot, M, N, E, n11, N, G); });
+            best = std::min(best, t1 + t2);
+        }
+        printf("iteration: C2 %.3f ms (%.1f %% vs A %.3f ms)\n", best, 100.0 * best / (acn + avn) - 100.0, acn + avn);
+    }
     printf("iteration: B' %.3f ms (%.1f %%)\n", b2cn + b2vn, 100.0 * (b2cn + b2vn) / (acn + avn) - 100.0);
     printf("iteration: A %.3f ms   B %.3f ms (%.1f %%)   B(nt) %.3f ms (%.1f %%)\n", acn + avn, bcn + bvn, 100.0 * (bcn + bvn) / (acn + avn) - 100.0,
            bcn2 + bvn, 100.0 * (bcn2 + bvn) / (acn + avn) - 100.0);
