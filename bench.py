@@ -242,9 +242,12 @@ def main():
         dec = make_decoder(True)
         dte = timed(dec, max(1, args.steps), 1)
         g2, its2, n2 = verdicts(dec)
+        st = dec.last_run_stats()
         early = dict(value=g2 * K * max(1, args.steps) / dte / 1e6, unit="Mbit/s", fer=1.0 - g2 / n2,
                      avg_iterations=its2 / n2, iterations_launched=dec.last_run_iterations,
-                     ms_per_step=dte / max(1, args.steps) * 1e3)
+                     ms_per_step=dte / max(1, args.steps) * 1e3,
+                     # sum of the frames' iteration counts / lane-iterations the groups executed (rank 0's shard)
+                     useful_work=float(dec.fetch_status()[0].sum().item()) / max(1, st["lane_iterations"]), compactions=st["compactions"])
         del dec
         torch.cuda.empty_cache()
 
@@ -263,9 +266,11 @@ def main():
             ks = {s["name"]: s for s in dec.profile_read()}
             dec.profile(False)
             gh, ith, nh = verdicts(dec)
+            sth = dec.last_run_stats()
             cnh, vnh = ks["cn_update"], ks["vn_update"]
             res[name] = dict(value=gh * K * max(1, args.steps) / dth / 1e6, unit="Mbit/s", fer=1.0 - gh / nh, avg_iterations=ith / nh,
                              ms_per_step=dth / max(1, args.steps) * 1e3,
+                             useful_work=(float(dec.fetch_status()[0].sum().item()) / max(1, sth["lane_iterations"])) if synd else 1.0, compactions=sth["compactions"],
                              cn_update_GBs=(cnh["alg_bytes"] / cnh["launches"]) / (cnh["total_ms"] / cnh["launches"] * 1e-3) / 1e9,
                              vn_update_GBs=(vnh["alg_bytes"] / vnh["launches"]) / (vnh["total_ms"] / vnh["launches"] * 1e-3) / 1e9)
             del dec

@@ -178,7 +178,13 @@ typedef struct qldpc_decoder_cfg {
                             oracle's integer decoder; qldpc_fetch_post_dev then returns the integer posteriors           */
     float quant_scale;   /* msg_dtype 2: quantiser steps per LLR unit (0 = 8.0); OMS offset = rint(rule_param * quant_scale)
                             steps, NMS factor = rint(rule_param * 128) / 128                                          */
-    int reserved[3];     /* must be zero                                                         */
+    int compact;         /* FRAMES engine, flooding, enable_syndrome, freeze_messages = 0: active-frame compaction.
+                            Once the frames that have not converged fit into <= 0.6 of the groups in flight they are dealt into fewer,
+                            full groups (the message arrays are not copied: the next check pass reads them through a slot map), so a
+                            group no longer runs until its slowest frame.  Decisions, iteration counts and success flags are unchanged;
+                            qldpc_fetch_post_dev is refused after a run that compacted.  0 = auto (batches of >= 4 groups), 1 = whenever
+                            a group can be saved, 2 = never                                                          */
+    int reserved[2];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
 void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg);
@@ -238,6 +244,9 @@ typedef struct qldpc_kernel_stat {
     uint64_t launches;
     double total_ms;      /* hipEvent time summed over launches                                   */
     double alg_bytes;     /* algorithmic bytes summed over launches         */
+    double moved_bytes;   /* bytes those launches have to move in the data form in use (e.g. with coded LLRs a
+                             variable-node pass fetches N/8 bytes of received-bit ballots per frame, not the 4 N bytes of an
+                             LLR array that alg_bytes prices): time these for the bandwidth actually sustained */
 } qldpc_kernel_stat;
 /* When on, every kernel launch is bracketed by hipEvents on the decoder's stream. */
 int qldpc_profile_enable(qldpc_decoder *dec, int on);
@@ -246,6 +255,11 @@ int qldpc_profile_read(qldpc_decoder *dec, qldpc_kernel_stat *out, int cap);
 int qldpc_profile_clear(qldpc_decoder *dec);
 /* Launches actually issued by the last qldpc_run (converged groups make later ones no-ops). */
 int qldpc_last_run_iterations(const qldpc_decoder *dec);
+/* Early-exit bookkeeping of the last qldpc_run (FRAMES engine; zeros otherwise): out[0] = lane-iterations executed (every
+ * iteration a group ran counts its whole width, converged lanes included -- divide the sum of the frames' iteration counts by it
+ * for the useful-work fraction), out[1] = compactions, out[2] = groups in flight at the end, out[3] = frames per group.
+ * Synchronises the decoder's stream. */
+int qldpc_last_run_stats(qldpc_decoder *dec, long long out[4]);
 
 /* ------------------------------------------------------------------ encoder (Alice) ---------- */
 /* method: "IRA" (dual-diagonal accumulate) or "IDENTITY" (GF(2) elimination, any full-rank H). */

@@ -61,11 +61,11 @@ _vp = C.c_void_p
 class DecoderCfg(C.Structure):
     _fields_ = [("schedule", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("n_ite", C.c_int),
                 ("enable_syndrome", C.c_int), ("syndrome_depth", C.c_int), ("max_frames", C.c_int),
-                ("device", C.c_int), ("frames_per_lane", C.c_int), ("engine", C.c_int), ("freeze_messages", C.c_int), ("msg_dtype", C.c_int), ("quant_scale", C.c_float), ("reserved", C.c_int * 3)]
+                ("device", C.c_int), ("frames_per_lane", C.c_int), ("engine", C.c_int), ("freeze_messages", C.c_int), ("msg_dtype", C.c_int), ("quant_scale", C.c_float), ("compact", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double), ("moved_bytes", C.c_double)]
 
 
 def _sig(name, res, args):
@@ -117,6 +117,7 @@ _sig("qldpc_profile_enable", C.c_int, [_vp, C.c_int])
 _sig("qldpc_profile_read", C.c_int, [_vp, C.POINTER(KernelStat), C.c_int])
 _sig("qldpc_profile_clear", C.c_int, [_vp])
 _sig("qldpc_last_run_iterations", C.c_int, [_vp])
+_sig("qldpc_last_run_stats", C.c_int, [_vp, C.POINTER(C.c_longlong)])
 _sig("qldpc_encoder_create", C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(_vp)])
 _sig("qldpc_encoder_free", None, [_vp])
 _sig("qldpc_encoder_k", C.c_int, [_vp])
@@ -274,7 +275,7 @@ class Decoder:
 
     def __init__(self, code, K, n_ite, info_bits_pos=None, rule="SPA", rule_param=0.0, enable_syndrome=True,
                  syndrome_depth=1, n_frames=1, schedule="flooding", device=0, frames_per_lane=0, engine="auto",
-                 freeze_messages=False, msg_dtype="f32", quant_scale=0.0):
+                 freeze_messages=False, msg_dtype="f32", quant_scale=0.0, compact="auto"):
         cfg = DecoderCfg()
         _L.qldpc_decoder_cfg_default(C.byref(cfg))
         cfg.schedule = SCHEDULES[schedule]
@@ -290,6 +291,7 @@ class Decoder:
         cfg.freeze_messages = int(bool(freeze_messages))
         cfg.msg_dtype = {"f32": 0, "f16": 1, "i8": 2}[msg_dtype]
         cfg.quant_scale = float(quant_scale)
+        cfg.compact = {"auto": 0, "on": 1, "off": 2}[compact]
         pos = None
         if info_bits_pos is not None:
             pos = _np_i32(info_bits_pos)
@@ -399,6 +401,12 @@ class Decoder:
     def last_run_iterations(self):
         return _L.qldpc_last_run_iterations(self._h)
 
+    def last_run_stats(self):
+        """Early-exit bookkeeping of the last run: lane-iterations executed, compactions, groups in flight at the end, frames per group."""
+        out = (C.c_longlong * 4)()
+        _chk(_L.qldpc_last_run_stats(self._h, out), "last_run_stats")
+        return dict(lane_iterations=int(out[0]), compactions=int(out[1]), final_groups=int(out[2]), frames_per_group=int(out[3]))
+
     # -- measurement ---------------------------------------------------------------------------
     def profile(self, on=True):
         _chk(_L.qldpc_profile_enable(self._h, int(on)), "profile")
@@ -410,7 +418,7 @@ class Decoder:
         arr = (KernelStat * 16)()
         n = _chk(_L.qldpc_profile_read(self._h, arr, 16), "profile_read")
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
-                     alg_bytes=float(arr[i].alg_bytes)) for i in range(n)]
+                     alg_bytes=float(arr[i].alg_bytes), moved_bytes=float(arr[i].moved_bytes)) for i in range(n)]
 
     def __del__(self):
         try:

@@ -15,21 +15,9 @@
 #include <new>
 #include <vector>
 
-#include "../../include/qldpc.h"
-#include "qldpc_graph.h"
-#include "qldpc_kernels.h"
+#include "qldpc_engine_int.h"
 #include "qldpc_kernels_edge.h"
-#include "qldpc_kernels_i8.h"
-#include "qldpc_kernels_h16.h"
-
-#define HIPCHK(expr)                                                                                    \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess) {                                                                        \
-            qldpc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));     \
-            return QLDPC_EHIP;                                                                          \
-        }                                                                                               \
-    } while (0)
+#include "qldpc_kernels_compact.h"
 
 extern "C" int qldpc_device_count(void)
 {
@@ -40,64 +28,9 @@ extern "C" int qldpc_device_count(void)
 
 /* ------------------------------------------------------------------ decoder object ----------- */
 
-enum { KS_CN = 0, KS_VN, KS_LAYER, KS_SYND, KS_STATUS, KS_LOAD, KS_FETCH, KS_COUNT };
-static const char *const ks_names[KS_COUNT] = {"cn_update", "vn_update", "layer_update", "syndrome", "status", "load", "fetch"};
-
-struct prof_rec { int kind; double bytes; hipEvent_t a, b; };
-
-struct bucket { int cap; int n; int *d_list; };   /* cap = register-resident degree bound, 0 = any degree */
-
-struct qldpc_decoder {
-    qldpc_decoder_cfg cfg;
-    int N, M, E, K;
-    int V, FG, G;
-    int device;
-    hipStream_t stream;
-    /* graph on device */
-    int *d_cn_ptr, *d_cn_tr, *d_cn_var, *d_vn_ptr, *d_info_pos;
-    std::vector<bucket> cn_buckets, vn_buckets;
-    std::vector<std::vector<bucket>> layer_buckets;   /* per layer */
-    int n_layers;
-    /* state */
-    float *d_llr, *d_a, *d_b;        /* flooding: a = v2c, b = c2v ; layered: a = post, b = msg */
-    float *d_post;                   /* lazily allocated by fetch_post */
-    u64 *d_sgn, *d_hard, *d_unsat, *d_done;
-    int *d_depth, *d_iters, *d_active;
-    int *h_active;                   /* pinned */
-    size_t bytes;
-    int n_frames;                    /* loaded */
-    int loaded, ran;
-    int last_iters;
-    int poll_every;
-    u64 *d_synd;                     /* [G][M][V] target-syndrome ballots (syndrome form), NULL until used */
-    uint32_t *e_synd;                /* edge engine: packed target syndromes [F][Wm] */
-    int has_synd;
-    float *h_in; int *h_out;         /* device staging of qldpc_decode_siho's host vectors */
-    int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
-    /* coded channel LLRs (flooding, fp32 / binary16 messages, after qldpc_load_bits_*): no LLR array is read, see qk_coded_llr */
-    u64 *d_ybits; float *d_fmag; int *d_fnch; uint8_t *d_vcls; int llr_coded;
-    int post_closes_run;             /* set around the _compute_post that ends an early-exit run (not for posterior read-back) */
-    int packed_h16;                  /* binary16 variant: use the packed check-node kernel when V == 2 (QLDPC_PACKED_H16=0 turns it off) */
-    int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */
-    uint32_t *d_llr8;                /* [G][N][256] quantised channel LLRs, four frames of a lane per dword */
-    float quant_scale;
-    int freeze;                      /* 1: lane-masked stores keep converged frames' messages bit-frozen (exact posteriors, slower) */
-    /* edge-parallel engine (one block at a time): llr [F][N], d_a = v2c / d_b = c2v [F][E] */
-    int engine, eW, eS, e_stride;
-    size_t e_lds;
-    uint32_t *e_sgn, *e_hard;
-    float *e_c2v1;                   /* odd-iteration chk_to_var buffer (d_b is the even one) */
-    int *e_unsat, *e_done_at;
-    int *h_done;
-    hipEvent_t e_ev[2];
-    int use_graphs, graph_frames;
-    hipStream_t cap_stream;
-    std::vector<hipGraphExec_t> e_graphs;   /* one per chunk of poll_every iterations */
-    /* profiling */
-    int prof_on;
-    std::vector<prof_rec> prof_pending;
-    qldpc_kernel_stat stats[KS_COUNT];
-};
+QLDPC_DECLARE_LAUNCH(1)
+QLDPC_DECLARE_LAUNCH(2)
+QLDPC_DECLARE_LAUNCH(4)
 
 static const int CN_CAPS[] = {8, 12, 20, 40};
 static const int VN_CAPS[] = {4, 12};
@@ -150,10 +83,13 @@ extern "C" void qldpc_decoder_cfg_default(qldpc_decoder_cfg *cfg)
     cfg->frames_per_lane = 0;
 }
 
+static void view_reset(qldpc_decoder *d);
+
 extern "C" void qldpc_decoder_free(qldpc_decoder *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    view_reset(d);      /* the d_* pointers freed below are the base arrays */
     if (d->stream) (void)hipStreamSynchronize(d->stream); else (void)hipDeviceSynchronize();
     for (auto &r : d->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto &b : d->cn_buckets) (void)hipFree(b.d_list);
@@ -170,6 +106,12 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     if (d->e_ev[0]) (void)hipEventDestroy(d->e_ev[0]);
     if (d->e_ev[1]) (void)hipEventDestroy(d->e_ev[1]);
     if (d->h_active) (void)hipHostFree(d->h_active);
+    (void)hipFree(d->d_work); (void)hipFree(d->d_gcount); (void)hipFree(d->d_goff); (void)hipFree(d->d_llr_alt[0]); (void)hipFree(d->d_llr_alt[1]); (void)hipFree(d->d_llr8_alt[0]); (void)hipFree(d->d_llr8_alt[1]);
+    for (size_t k = 1; k < d->gens.size(); k++) {
+        gen_state &n = d->gens[k];
+        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd);
+        (void)hipFree(n.depth); (void)hipFree(n.iters); (void)hipFree(n.origin); (void)hipFree(n.src); (void)hipFree(n.fmag); (void)hipFree(n.fnch);
+    }
     delete d;
 }
 
@@ -314,8 +256,21 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if ((rc = dev_alloc(d, &d->d_done, G * V))) return rc;
     if ((rc = dev_alloc(d, &d->d_depth, G * FG))) return rc;
     if ((rc = dev_alloc(d, &d->d_iters, G * FG))) return rc;
-    if ((rc = dev_alloc(d, &d->d_active, 1))) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_active, sizeof(int)));
+    if ((rc = dev_alloc(d, &d->d_active, 2))) return rc;
+    if ((rc = dev_alloc(d, &d->d_work, 1))) return rc;
+    HIPCHK(hipHostMalloc((void **)&d->h_active, 2 * sizeof(int)));
+    /* active-frame compaction (early exit, flooding, messages not frozen): reserved[0] = 0 auto (batches of >= 4 groups), 1 always, 2 never */
+    d->G0 = d->G;
+    d->compact_mode = cfg->compact;
+    if (const char *e = getenv("QLDPC_COMPACT")) d->compact_mode = atoi(e);
+    d->compact_ratio = 0.6f;
+    if (const char *e = getenv("QLDPC_COMPACT_RATIO")) { const float x = (float)atof(e); if (x > 0.0f && x <= 1.0f) d->compact_ratio = x; }
+    if (!cfg->enable_syndrome || cfg->schedule != QLDPC_SCHED_FLOODING || d->freeze || (d->compact_mode == 0 && d->G < 4)) d->compact_mode = 2;
+    if (d->compact_mode != 2) {
+        if ((rc = dev_alloc(d, &d->d_gcount, (size_t)d->G))) return rc;
+        if ((rc = dev_alloc(d, &d->d_goff, (size_t)d->G + 1))) return rc;
+        if (d->poll_every != 1 && !getenv("QLDPC_POLL_EVERY")) d->poll_every = 1;      /* a compaction is decided on the count the status pass leaves */
+    }
     return QLDPC_OK;
 }
 
@@ -333,6 +288,7 @@ extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *in
     if (cfg->enable_syndrome && cfg->syndrome_depth < 1) { qldpc_set_error("decoder_create: syndrome_depth=%d", cfg->syndrome_depth); return QLDPC_EINVAL; }
     if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 && cfg->frames_per_lane != 4) { qldpc_set_error("decoder_create: frames_per_lane=%d", cfg->frames_per_lane); return QLDPC_EINVAL; }
     if (cfg->msg_dtype < 0 || cfg->msg_dtype > 2) { qldpc_set_error("decoder_create: msg_dtype=%d", cfg->msg_dtype); return QLDPC_EINVAL; }
+    if (cfg->compact < 0 || cfg->compact > 2 || cfg->reserved[0] || cfg->reserved[1]) { qldpc_set_error("decoder_create: compact=%d (0 auto, 1 on, 2 off), reserved words must be zero", cfg->compact); return QLDPC_EINVAL; }
     if (!(cfg->quant_scale >= 0.0f) || cfg->quant_scale > 64.0f) { qldpc_set_error("decoder_create: quant_scale=%g", (double)cfg->quant_scale); return QLDPC_EINVAL; }
     qldpc_decoder *d = new (std::nothrow) qldpc_decoder();
     if (!d) return QLDPC_ENOMEM;
@@ -340,6 +296,30 @@ extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *in
     if (rc != QLDPC_OK) { qldpc_decoder_free(d); return rc; }
     *out = d;
     return QLDPC_OK;
+}
+
+/* ---- generations of the per-frame state (active-frame compaction) ---------------------------- */
+
+static void use_gen(qldpc_decoder *d, int k)
+{
+    const gen_state &n = d->gens[(size_t)k];
+    d->G = n.G;
+    d->d_sgn = n.sgn; d->d_hard = n.hard; d->d_unsat = n.unsat; d->d_done = n.done; d->d_ybits = n.ybits; d->d_synd = n.synd;
+    d->d_depth = n.depth; d->d_iters = n.iters; d->d_fmag = n.fmag; d->d_fnch = n.fnch; d->d_llr = n.llr; d->d_llr8 = n.llr8;
+}
+/* back to the batch as loaded (generation 0 = the decoder's base arrays) */
+static void view_reset(qldpc_decoder *d)
+{
+    if (d->cur_gen != 0) { use_gen(d, 0); d->cur_gen = 0; }
+    d->remap_src = nullptr;
+}
+static void gen0_capture(qldpc_decoder *d)
+{
+    if (d->gens.empty()) d->gens.resize(1);
+    gen_state &n = d->gens[0];
+    n.G = n.cap = d->G0;
+    n.sgn = d->d_sgn; n.hard = d->d_hard; n.unsat = d->d_unsat; n.done = d->d_done; n.ybits = d->d_ybits; n.synd = d->d_synd;
+    n.depth = d->d_depth; n.iters = d->d_iters; n.origin = nullptr; n.src = nullptr; n.fmag = d->d_fmag; n.fnch = d->d_fnch; n.llr = d->d_llr; n.llr8 = d->d_llr8;
 }
 
 static int ensure_llr(qldpc_decoder *d)
@@ -352,11 +332,28 @@ extern "C" int qldpc_decoder_set_stream(qldpc_decoder *d, void *s) { if (!d) ret
 extern "C" size_t qldpc_decoder_device_bytes(const qldpc_decoder *d) { return d ? d->bytes : 0; }
 extern "C" int qldpc_last_run_iterations(const qldpc_decoder *d) { return d ? d->last_iters : QLDPC_EINVAL; }
 
+/* early-exit bookkeeping of the last run (FRAMES engine): out[0] = lane-iterations executed (groups that ran an iteration x frames
+ * per group, counted by the status pass), out[1] = compactions, out[2] = groups in the last generation, out[3] = frames per group.
+ * Synchronises the stream. */
+extern "C" int qldpc_last_run_stats(qldpc_decoder *d, long long out[4])
+{
+    if (!d || !out) return QLDPC_EINVAL;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (d->engine == QLDPC_ENGINE_EDGES || !d->d_work) return QLDPC_OK;
+    HIPCHK(hipSetDevice(d->device));
+    unsigned long long w = 0;
+    HIPCHK(hipMemcpyAsync(&w, d->d_work, sizeof(w), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    out[0] = (long long)w * d->FG; out[1] = d->compactions; out[2] = d->G; out[3] = d->FG;
+    return QLDPC_OK;
+}
+
 /* reset(): the next decode starts from chk_to_var = 0 (BS/src/main.cpp:389).  Every qldpc_run starts
  * from that state anyway (frames are independent decodes), so this only drops loaded frames. */
 extern "C" int qldpc_decoder_reset(qldpc_decoder *d)
 {
     if (!d) return QLDPC_EINVAL;
+    view_reset(d);
     d->loaded = 0; d->ran = 0; d->n_frames = 0;
     return QLDPC_OK;
 }
@@ -372,14 +369,14 @@ extern "C" int qldpc_sync(qldpc_decoder *d)
 /* ------------------------------------------------------------------ profiling ---------------- */
 
 struct prof_scope {
-    qldpc_decoder *d; int kind; double bytes; hipEvent_t a, b; bool on;
-    prof_scope(qldpc_decoder *d_, int kind_, double bytes_) : d(d_), kind(kind_), bytes(bytes_), a(nullptr), b(nullptr), on(d_->prof_on != 0)
+    qldpc_decoder *d; int kind; double bytes, moved; hipEvent_t a, b; bool on;
+    prof_scope(qldpc_decoder *d_, int kind_, double bytes_, double moved_ = -1.0) : d(d_), kind(kind_), bytes(bytes_), moved(moved_ < 0.0 ? bytes_ : moved_), a(nullptr), b(nullptr), on(d_->prof_on != 0)
     {
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->stream); }
     }
     ~prof_scope()
     {
-        if (on) { (void)hipEventRecord(b, d->stream); d->prof_pending.push_back({kind, bytes, a, b}); }
+        if (on) { (void)hipEventRecord(b, d->stream); d->prof_pending.push_back({kind, bytes, moved, a, b}); }
     }
 };
 
@@ -395,6 +392,7 @@ static int prof_fold(qldpc_decoder *d)
             d->stats[r.kind].launches++;
             d->stats[r.kind].total_ms += ms;
             d->stats[r.kind].alg_bytes += r.bytes;
+            d->stats[r.kind].moved_bytes += r.moved;
         }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
@@ -418,217 +416,48 @@ extern "C" int qldpc_profile_clear(qldpc_decoder *d)
     if (!d) return QLDPC_EINVAL;
     int rc = prof_fold(d);
     if (rc) return rc;
-    for (int k = 0; k < KS_COUNT; k++) { d->stats[k].launches = 0; d->stats[k].total_ms = 0; d->stats[k].alg_bytes = 0; }
+    for (int k = 0; k < KS_COUNT; k++) { d->stats[k].launches = 0; d->stats[k].total_ms = 0; d->stats[k].alg_bytes = 0; d->stats[k].moved_bytes = 0; }
     return QLDPC_OK;
 }
 
 /* ------------------------------------------------------------------ launch helpers ----------- */
 
-#define LAUNCHCHK()                                                                                     \
-    do {                                                                                                \
-        hipError_t e__ = hipGetLastError();                                                             \
-        if (e__ != hipSuccess) { qldpc_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); return QLDPC_EHIP; } \
-    } while (0)
-
-static inline int grid_x(int n_items, int per_wave)
-{
-    const int per_block = QK_WAVES * per_wave;
-    return std::max(1, (n_items + per_block - 1) / per_block);
-}
-
-static int family_of(int rule)
-{
-    switch (rule) {
-    case QLDPC_RULE_MS: case QLDPC_RULE_OMS: case QLDPC_RULE_NMS: return QK_FAM_MS;
-    case QLDPC_RULE_SPA: return QK_FAM_SPA;
-    case QLDPC_RULE_LSPA: return QK_FAM_LSPA;
-    default: return QK_FAM_AMS;
-    }
-}
-
-/* the rule in quantiser units (qldpc.h: quant_scale) */
-static qi_rule qi_rule_of(const qldpc_decoder *d)
-{
-    qi_rule qr{d->cfg.rule, 0};
-    if (d->cfg.rule == QLDPC_RULE_OMS) qr.param = (int)lrintf(d->cfg.rule_param * d->quant_scale);
-    if (d->cfg.rule == QLDPC_RULE_NMS) qr.param = (int)lrintf(d->cfg.rule_param * 128.0f);
-    qr.param = std::min(128, std::max(0, qr.param));
-    return qr;
-}
-
-template <int V, int CAP, int FAM>
-static void launch_cn_one(qldpc_decoder *d, const bucket &b, bool first)
-{
-    dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
-    qk_rule r{d->cfg.rule, d->cfg.rule_param};
-    if (first && !d->msg_i8) {      /* iteration 0 with coded LLRs: inputs rebuilt from the received bits, var_to_chk is not read (see qk_cn_flood FIRST) */
-        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
-        if (d->msg_half)
-            hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half, true>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
-                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->d_cn_var, d->N, c);
-        else
-            hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, float, true>), grid, dim3(QK_THREADS), 0, d->stream, (const float *)d->d_a, d->d_b, b.d_list, b.n,
-                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->d_cn_var, d->N, c);
-        return;
-    }
-    if (d->msg_i8) {
-        if constexpr (V == QI_V && FAM == QK_FAM_MS) {
-            if (first)
-                hipLaunchKernelGGL((qi_cn_flood<CAP, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
-                                   d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M, d->d_llr8, d->d_cn_var, d->N);
-            else
-                hipLaunchKernelGGL((qi_cn_flood<CAP, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
-                                   d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M, (const uint32_t *)nullptr, (const int *)nullptr, 0);
-        }
-        return;
-    }
-    if (d->msg_half && !d->freeze && d->packed_h16) {
-        if constexpr (V == 2 && FAM == QK_FAM_MS && CAP > 0) {      /* packed binary16 fold (qldpc_kernels_h16.h), bit-identical */
-            hipLaunchKernelGGL((qh_cn_flood<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n,
-                               d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * 64, d->d_done, r, d->has_synd ? d->d_synd : nullptr, d->M);
-            return;
-        }
-    }
-    if (d->msg_half)
-        hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
-                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
-    else
-        hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, float>), grid, dim3(QK_THREADS), 0, d->stream, (const float *)d->d_a, d->d_b, b.d_list, b.n,
-                           d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
-}
-template <int V, int FAM>
-static void launch_cn_fam(qldpc_decoder *d, const bucket &b, bool first)
-{
-    switch (b.cap) {
-    case 8: launch_cn_one<V, 8, FAM>(d, b, first); break;
-    case 12: launch_cn_one<V, 12, FAM>(d, b, first); break;
-    case 20: launch_cn_one<V, 20, FAM>(d, b, first); break;
-    case 40: launch_cn_one<V, 40, FAM>(d, b, first); break;
-    default: launch_cn_one<V, 0, FAM>(d, b, first); break;
-    }
-}
-template <int V>
-static void launch_cn(qldpc_decoder *d, const bucket &b, bool first)
-{
-    switch (family_of(d->cfg.rule)) {
-    case QK_FAM_MS: launch_cn_fam<V, QK_FAM_MS>(d, b, first); break;
-    case QK_FAM_SPA: launch_cn_fam<V, QK_FAM_SPA>(d, b, first); break;
-    case QK_FAM_LSPA: launch_cn_fam<V, QK_FAM_LSPA>(d, b, first); break;
-    default: launch_cn_fam<V, QK_FAM_AMS>(d, b, first); break;
-    }
-}
-
-template <int V, int CAP, int FAM>
-static void launch_layer_one(qldpc_decoder *d, const bucket &b)
-{
-    dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
-    qk_rule r{d->cfg.rule, d->cfg.rule_param};
-    if (d->msg_i8) {
-        if constexpr (V == QI_V && FAM == QK_FAM_MS)
-            hipLaunchKernelGGL((qi_cn_layer<CAP>), grid, dim3(QK_THREADS), 0, d->stream, (uint32_t *)d->d_a, (uint32_t *)d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                               d->N, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
-        return;
-    }
-    hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
-}
-template <int V, int FAM>
-static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
-{
-    switch (b.cap) {
-    case 8: launch_layer_one<V, 8, FAM>(d, b); break;
-    case 12: launch_layer_one<V, 12, FAM>(d, b); break;
-    case 20: launch_layer_one<V, 20, FAM>(d, b); break;
-    case 40: launch_layer_one<V, 40, FAM>(d, b); break;
-    default: launch_layer_one<V, 0, FAM>(d, b); break;
-    }
-}
-template <int V>
-static void launch_layer(qldpc_decoder *d, const bucket &b)
-{
-    switch (family_of(d->cfg.rule)) {
-    case QK_FAM_MS: launch_layer_fam<V, QK_FAM_MS>(d, b); break;
-    case QK_FAM_SPA: launch_layer_fam<V, QK_FAM_SPA>(d, b); break;
-    case QK_FAM_LSPA: launch_layer_fam<V, QK_FAM_LSPA>(d, b); break;
-    default: launch_layer_fam<V, QK_FAM_AMS>(d, b); break;
-    }
-}
-
-/* the in-between variable-node passes only need to leave ballots when the syndrome test reads them; _compute_post always does */
-static int want_ballots(const qldpc_decoder *d, int mode)
-{
-    if (mode == QK_VN_POST) return 1 | (d->post_closes_run ? 2 : 0);      /* bit 1: skip groups that converged as a whole (their ballots are final) */
-    return d->cfg.enable_syndrome ? 1 : 0;
-}
-
-template <int V, int CAP, int UNX, int MODE, typename MT>
-static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
-{
-    dim3 grid((unsigned)grid_x(b.n, UNX), (unsigned)d->G);
-    if (d->llr_coded) {
-        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
-        hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, true>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, (const float *)nullptr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c, want_ballots(d, MODE));
-        return;
-    }
-    hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, false>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{}, want_ballots(d, MODE));
-}
-template <int V, int CAP, int MODE>
-static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
-{
-    constexpr int UN = (CAP > 0 && CAP <= 4) ? 4 : 2;
-    if (d->msg_i8) {
-        if constexpr (V == QI_V) {
-            dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
-            if (d->llr_coded) {
-                qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
-                hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, (const uint32_t *)nullptr, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale, want_ballots(d, MODE));
-            } else
-                hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f, want_ballots(d, MODE));
-        }
-        return;
-    }
-    if (d->msg_half) launch_vn_k<V, CAP, UN, MODE, __half>(d, b, post_out);
-    else launch_vn_k<V, CAP, UN, MODE, float>(d, b, post_out);
-}
-template <int V, int MODE>
-static void launch_vn(qldpc_decoder *d, const bucket &b, float *post_out)
-{
-    if (MODE == QK_VN_FIRST) { launch_vn_one<V, 0, MODE>(d, b, post_out); return; }
-    switch (b.cap) {
-    case 4: launch_vn_one<V, 4, MODE>(d, b, post_out); break;
-    case 12: launch_vn_one<V, 12, MODE>(d, b, post_out); break;
-    default: launch_vn_one<V, 0, MODE>(d, b, post_out); break;
-    }
-}
-
 /* algorithmic bytes: only live (non-padding) frames are counted */
 static double msg_b(const qldpc_decoder *d) { return d->msg_i8 ? 1.0 : (d->msg_half ? 2.0 : 4.0); }
 static double llr_b(const qldpc_decoder *d) { return d->msg_i8 ? 1.0 : 4.0; }
-static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * msg_b(d) * d->n_frames; }
+/* frames the next launches work on: all loaded frames, or -- once the early-exit loop has polled -- the lanes of the groups still active */
+static double live_frames(const qldpc_decoder *d) { return (double)(d->live_lanes > 0 && d->live_lanes < d->n_frames ? d->live_lanes : d->n_frames); }
+static double bytes_cn(const qldpc_decoder *d) { return 2.0 * d->E * msg_b(d) * live_frames(d); }
 static double bytes_vn(const qldpc_decoder *d, int mode)
 {
-    if (mode == QK_VN_FIRST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
-    if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
-    return (2.0 * d->E * msg_b(d) + d->N * llr_b(d)) * d->n_frames;
+    if (mode == QK_VN_FIRST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * live_frames(d);
+    if (mode == QK_VN_POST) return ((double)d->E * msg_b(d) + d->N * llr_b(d)) * live_frames(d);
+    return (2.0 * d->E * msg_b(d) + d->N * llr_b(d)) * live_frames(d);
 }
-static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * msg_b(d) * d->n_frames; }
+/* what a variable-node pass has to fetch in the data form in use: with coded LLRs the channel values are N/8 bytes of received-bit
+ * ballots per frame (plus a class byte per VN, shared by all frames) instead of an N * llr_b array */
+static double moved_vn(const qldpc_decoder *d, int mode)
+{
+    if (!d->llr_coded) return bytes_vn(d, mode);
+    const double msgs = (mode == QK_VN_NORMAL ? 2.0 : 1.0) * d->E * msg_b(d);
+    return (msgs + d->N / 8.0) * live_frames(d) + d->N;
+}
+static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * msg_b(d) * live_frames(d); }
 
 template <int V, int MODE>
 static int vn_pass(qldpc_decoder *d, float *post_out)
 {
-    prof_scope ps(d, KS_VN, bytes_vn(d, MODE));
-    for (auto &b : d->vn_buckets) { launch_vn<V, MODE>(d, b, post_out); LAUNCHCHK(); }
+    prof_scope ps(d, KS_VN, bytes_vn(d, MODE), moved_vn(d, MODE));
+    for (auto &b : d->vn_buckets) { qldpc_launch_vn<V, MODE>(d, b, post_out); LAUNCHCHK(); }
     return QLDPC_OK;
 }
 template <int V>
 static int cn_pass(qldpc_decoder *d, bool first = false)
 {
-    prof_scope ps(d, KS_CN, bytes_cn(d));
-    for (auto &b : d->cn_buckets) { launch_cn<V>(d, b, first); LAUNCHCHK(); }
+    /* the first pass with coded LLRs reads ballots instead of var_to_chk rows */
+    prof_scope ps(d, KS_CN, bytes_cn(d), first && !d->msg_i8 ? ((double)d->E * msg_b(d) + d->N / 8.0) * live_frames(d) : -1.0);
+    for (auto &b : d->cn_buckets) { qldpc_launch_cn<V>(d, b, first); LAUNCHCHK(); }
+    d->remap_src = nullptr;      /* chk_to_var is in the current generation's layout now, and so is everything after it */
     return QLDPC_OK;
 }
 template <int V>
@@ -645,18 +474,86 @@ template <int V>
 static int status_pass(qldpc_decoder *d, int ite_done)
 {
     prof_scope ps(d, KS_STATUS, 0.0);
-    HIPCHK(hipMemsetAsync(d->d_active, 0, sizeof(int), d->stream));
+    HIPCHK(hipMemsetAsync(d->d_active, 0, 2 * sizeof(int), d->stream));
     hipLaunchKernelGGL((qk_status<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->G,
-                       d->cfg.syndrome_depth, ite_done, d->d_active);
+                       d->cfg.syndrome_depth, ite_done, d->d_active, d->d_work);
     LAUNCHCHK();
     return QLDPC_OK;
 }
-/* blocking: how many groups still have unconverged frames */
-static int poll_active(qldpc_decoder *d, int *active)
+/* blocking: how many groups still have unconverged frames, and how many frames those are */
+static int poll_active(qldpc_decoder *d, int *active, int *active_frames = nullptr)
 {
-    HIPCHK(hipMemcpyAsync(d->h_active, d->d_active, sizeof(int), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(d->h_active, d->d_active, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    *active = *d->h_active;
+    *active = d->h_active[0];
+    if (active_frames) *active_frames = d->h_active[1];
+    return QLDPC_OK;
+}
+
+/*
+ * Open the next generation: the `active_frames` frames that have not converged move into ceil(active_frames / FG) full groups
+ * (qldpc_kernels_compact.h).  The message arrays are not touched: the next check pass reads through d->remap_src.
+ */
+template <typename T> static int gen_alloc(qldpc_decoder *d, T **p, size_t n) { return *p ? QLDPC_OK : dev_alloc(d, p, n); }
+
+template <int V>
+static int compact(qldpc_decoder *d, int active_frames)
+{
+    int rc;
+    const int FG = d->FG, k = d->cur_gen + 1;
+    const int Gn = (active_frames + FG - 1) / FG;
+    if ((int)d->gens.size() <= k) d->gens.resize((size_t)k + 1);
+    const gen_state o = d->gens[(size_t)k - 1];
+    gen_state &n = d->gens[(size_t)k];
+    if (n.cap < Gn) {      /* first use (or a larger need than any run before): sized for the largest batch this generation can get */
+        (void)hipStreamSynchronize(d->stream);
+        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd);
+        (void)hipFree(n.depth); (void)hipFree(n.iters); (void)hipFree(n.origin); (void)hipFree(n.src); (void)hipFree(n.fmag); (void)hipFree(n.fnch);
+        n = gen_state{};
+        n.cap = std::max(Gn, std::min(o.cap, (int)(d->compact_ratio * (float)o.cap) + 1));
+    }
+    const size_t C = (size_t)n.cap;
+    if ((rc = gen_alloc(d, &n.sgn, C * d->N * V))) return rc;
+    if (d->msg_i8) n.hard = n.sgn;
+    else if ((rc = gen_alloc(d, &n.hard, C * d->N * V))) return rc;
+    if ((rc = gen_alloc(d, &n.unsat, C * V)) || (rc = gen_alloc(d, &n.done, C * V))) return rc;
+    if ((rc = gen_alloc(d, &n.depth, C * FG)) || (rc = gen_alloc(d, &n.iters, C * FG)) || (rc = gen_alloc(d, &n.origin, C * FG)) || (rc = gen_alloc(d, &n.src, C * FG))) return rc;
+    if (o.fmag && ((rc = gen_alloc(d, &n.fmag, C * FG)) || (rc = gen_alloc(d, &n.fnch, C * FG)))) return rc;
+    if (d->llr_coded && (rc = gen_alloc(d, &n.ybits, C * d->N * V))) return rc;
+    if (d->has_synd && (rc = gen_alloc(d, &n.synd, C * d->M * V))) return rc;
+    n.G = Gn;
+    n.llr = nullptr; n.llr8 = nullptr;
+    const bool rows8 = !d->llr_coded && d->msg_i8, rows32 = !d->llr_coded && !d->msg_i8;
+    if (rows8 || rows32) {      /* the decoder reads an LLR array: its rows move too, ping-pong between two side buffers (the loaded batch stays intact) */
+        const int side = k & 1;
+        if (d->llr_alt_cap[side] < n.cap) {      /* sized by the first generation that uses it (later ones are smaller); grows if a later batch needs more */
+            (void)hipStreamSynchronize(d->stream);
+            (void)hipFree(d->d_llr_alt[side]); (void)hipFree(d->d_llr8_alt[side]);
+            d->d_llr_alt[side] = nullptr; d->d_llr8_alt[side] = nullptr;
+            d->llr_alt_cap[side] = n.cap;
+        }
+        const size_t need = (size_t)d->llr_alt_cap[side] * d->N * (rows8 ? 64 : (size_t)FG);
+        if (rows8 && !d->d_llr8_alt[side] && (rc = dev_alloc(d, &d->d_llr8_alt[side], need))) return rc;
+        if (rows32 && !d->d_llr_alt[side] && (rc = dev_alloc(d, &d->d_llr_alt[side], need))) return rc;
+        n.llr8 = rows8 ? d->d_llr8_alt[side] : nullptr; n.llr = rows32 ? d->d_llr_alt[side] : nullptr;
+    }
+    prof_scope ps(d, KS_STATUS, 0.0);
+    hipLaunchKernelGGL((qk_compact_count<V>), dim3((unsigned)((o.G + 255) / 256)), dim3(256), 0, d->stream, o.done, d->d_gcount, o.G);
+    hipLaunchKernelGGL(qk_compact_scan, dim3(1), dim3(256), 0, d->stream, d->d_gcount, d->d_goff, o.G);
+    hipLaunchKernelGGL((qk_compact_scatter<V>), dim3((unsigned)o.G), dim3(64), 0, d->stream, o.done, d->d_goff, n.src);
+    hipLaunchKernelGGL((qk_compact_fill<V>), dim3((unsigned)Gn), dim3(64), 0, d->stream, n.src, d->d_goff + o.G, o.origin, n.origin, o.fmag, n.fmag, o.fnch, n.fnch,
+                       o.depth, n.depth, n.iters, n.done, n.unsat, d->cfg.n_ite, d->N);
+    LAUNCHCHK();
+    if (d->llr_coded) hipLaunchKernelGGL((qk_compact_ballots<V>), dim3((unsigned)((d->N + 64 * QK_WAVES - 1) / (64 * QK_WAVES)), (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.ybits, n.ybits, n.src, d->N);
+    if (d->has_synd) hipLaunchKernelGGL((qk_compact_ballots<V>), dim3((unsigned)((d->M + 64 * QK_WAVES - 1) / (64 * QK_WAVES)), (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.synd, n.synd, n.src, d->M);
+    const unsigned bx = (unsigned)std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, Gn)));
+    if (rows32) hipLaunchKernelGGL((qk_compact_rows<V, float>), dim3(bx, (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.llr, n.llr, n.src, d->N, 1.0f);
+    if (rows8) hipLaunchKernelGGL((qk_compact_rows<V, uint8_t>), dim3(bx, (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, (const uint8_t *)o.llr8, (uint8_t *)n.llr8, n.src, d->N, (uint8_t)0);
+    LAUNCHCHK();
+    d->cur_gen = k;
+    use_gen(d, k);
+    d->remap_src = n.src;
+    d->compactions++;
     return QLDPC_OK;
 }
 
@@ -680,9 +577,16 @@ static int run_flooding(qldpc_decoder *d)
             if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
             if ((rc = status_pass<V>(d, ite + 1))) return rc;
             if (d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {
-                int active = 1;
-                if ((rc = poll_active(d, &active))) return rc;
+                int active = 1, left = 0;
+                if ((rc = poll_active(d, &active, &left))) return rc;
+                d->live_lanes = active * d->FG;
                 if (active == 0) { ite++; break; }
+                /* few enough frames left: deal them into fewer, full groups (the next check pass reads through the slot map) */
+                const int Gn = (left + d->FG - 1) / d->FG;
+                if (d->compact_mode != 2 && d->cur_gen + 1 < QLDPC_MAX_GENS && ite + 2 < n_ite && Gn < d->G &&
+                    (d->compact_mode == 1 || (float)Gn <= d->compact_ratio * (float)d->G)) {
+                    if ((rc = compact<V>(d, left))) return rc;
+                }
             }
         }
     }
@@ -714,7 +618,7 @@ static int run_layered(qldpc_decoder *d)
         {
             prof_scope ps(d, KS_LAYER, bytes_layer(d));
             for (int l = 0; l < d->n_layers; l++)
-                for (auto &b : d->layer_buckets[(size_t)l]) { launch_layer<V>(d, b); LAUNCHCHK(); }
+                for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
             ballots();
@@ -737,16 +641,42 @@ static int run_layered(qldpc_decoder *d)
 template <int V>
 static int run_v(qldpc_decoder *d)
 {
+    view_reset(d);
+    gen0_capture(d);
+    d->compactions = 0;
+    d->live_lanes = 0;
     {
         prof_scope ps(d, KS_STATUS, 0.0);
-        hipLaunchKernelGGL((qk_status_init<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->n_frames, d->cfg.n_ite);
+        hipLaunchKernelGGL((qk_status_init<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->n_frames, d->cfg.n_ite, d->d_work);
         LAUNCHCHK();
     }
     int rc = d->cfg.schedule == QLDPC_SCHED_FLOODING ? run_flooding<V>(d) : run_layered<V>(d);
     if (rc) return rc;
-    /* success flag: syndrome of the hard decision (all frames) */
-    HIPCHK(hipMemsetAsync(d->d_unsat, 0, sizeof(u64) * (size_t)d->G * V, d->stream));
-    return synd_pass<V>(d, d->d_hard, 0);
+    /* success flag: syndrome of the hard decision, in every generation (a frame's result lives where it converged) */
+    const int last = d->cur_gen;
+    for (int k = 0; k <= last && !rc; k++) {
+        use_gen(d, k);
+        if (hipMemsetAsync(d->d_unsat, 0, sizeof(u64) * (size_t)d->G * V, d->stream) != hipSuccess) rc = QLDPC_EHIP;
+        if (!rc) rc = synd_pass<V>(d, d->d_hard, 0);
+    }
+    use_gen(d, last);
+    return rc;
+}
+
+/* fn(origin, final_mask, n_slots) once per generation, with that generation's view in place: which slots hold a frame's result
+ * and where it belongs in the caller's batch (qk_result_frame) */
+template <typename F>
+static int for_each_gen(qldpc_decoder *d, F fn)
+{
+    const int last = d->cur_gen;
+    int rc = QLDPC_OK;
+    for (int k = 0; k <= last && !rc; k++) {
+        use_gen(d, k);
+        const gen_state &n = d->gens[(size_t)k];
+        rc = fn(n.origin, k < last ? (const u64 *)n.done : (const u64 *)nullptr, k == 0 ? d->n_frames : n.G * d->FG);
+    }
+    use_gen(d, last);
+    return rc;
 }
 
 /* ---- edge-parallel engine ----------------------------------------------------------------- */
@@ -917,6 +847,7 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
     int rc = check_frames(d, n_frames, "qldpc_load_llr_dev");
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
+    view_reset(d);
     d->n_frames = n_frames;
     d->has_synd = 0;
     d->llr_coded = 0;
@@ -959,6 +890,7 @@ extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bit
     int rc = check_frames(d, n_frames, "qldpc_load_bits_dev");
     if (rc) return rc;
     HIPCHK(hipSetDevice(d->device));
+    view_reset(d);
     d->n_frames = n_frames;
     d->has_synd = 0;
     const int W = (d->N + 31) / 32;
@@ -1025,6 +957,7 @@ extern "C" int qldpc_load_syndrome_dev(qldpc_decoder *d, const uint32_t *d_synd_
     if (!d || !d_synd_bits) return QLDPC_EINVAL;
     if (!d->loaded || n_frames != d->n_frames) { qldpc_set_error("qldpc_load_syndrome_dev: load %d frames first (have %d)", n_frames, d->loaded ? d->n_frames : 0); return QLDPC_ESTATE; }
     HIPCHK(hipSetDevice(d->device));
+    view_reset(d);
     const int Wm = (d->M + 31) / 32;
     int rc;
     if (d->engine == QLDPC_ENGINE_EDGES) {
@@ -1076,14 +1009,16 @@ extern "C" int qldpc_fetch_packed_dev(qldpc_decoder *d, uint32_t *d_out)
         HIPCHK(hipMemcpyAsync(d_out, d->e_hard, sizeof(uint32_t) * (size_t)d->n_frames * W, hipMemcpyDeviceToDevice, d->stream));
         return QLDPC_OK;
     }
-    dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
-    switch (d->V) {
-    case 1: hipLaunchKernelGGL((qk_fetch_packed<1>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
-    case 2: hipLaunchKernelGGL((qk_fetch_packed<2>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
-    default: hipLaunchKernelGGL((qk_fetch_packed<4>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, d->n_frames); break;
-    }
-    LAUNCHCHK();
-    return QLDPC_OK;
+    return for_each_gen(d, [&](const int *origin, const u64 *fin, int n_slots) -> int {
+        dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_fetch_packed<1>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, n_slots, origin, fin); break;
+        case 2: hipLaunchKernelGGL((qk_fetch_packed<2>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, n_slots, origin, fin); break;
+        default: hipLaunchKernelGGL((qk_fetch_packed<4>), grid, dim3(QK_THREADS), 0, d->stream, d->d_hard, d_out, d->N, W, n_slots, origin, fin); break;
+        }
+        LAUNCHCHK();
+        return (int)QLDPC_OK;
+    });
 }
 
 extern "C" int qldpc_fetch_info_dev(qldpc_decoder *d, int *d_V_K)
@@ -1099,13 +1034,16 @@ extern "C" int qldpc_fetch_info_dev(qldpc_decoder *d, int *d_V_K)
         LAUNCHCHK();
         return QLDPC_OK;
     }
-    switch (d->V) {
-    case 1: hipLaunchKernelGGL((qk_fetch_info<1>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
-    case 2: hipLaunchKernelGGL((qk_fetch_info<2>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
-    default: hipLaunchKernelGGL((qk_fetch_info<4>), grid, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, d->n_frames); break;
-    }
-    LAUNCHCHK();
-    return QLDPC_OK;
+    return for_each_gen(d, [&](const int *origin, const u64 *fin, int n_slots) -> int {
+        dim3 gk((unsigned)std::max(1, std::min((d->K + 255) / 256, 64)), (unsigned)n_slots);
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_fetch_info<1>), gk, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, n_slots, origin, fin); break;
+        case 2: hipLaunchKernelGGL((qk_fetch_info<2>), gk, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, n_slots, origin, fin); break;
+        default: hipLaunchKernelGGL((qk_fetch_info<4>), gk, dim3(256), 0, d->stream, d->d_hard, d->d_info_pos, d_V_K, d->N, d->K, n_slots, origin, fin); break;
+        }
+        LAUNCHCHK();
+        return (int)QLDPC_OK;
+    });
 }
 
 extern "C" int qldpc_fetch_status_dev(qldpc_decoder *d, int *d_iters, int *d_ok)
@@ -1120,13 +1058,16 @@ extern "C" int qldpc_fetch_status_dev(qldpc_decoder *d, int *d_iters, int *d_ok)
         LAUNCHCHK();
         return QLDPC_OK;
     }
-    switch (d->V) {
-    case 1: hipLaunchKernelGGL((qk_status_out<1>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
-    case 2: hipLaunchKernelGGL((qk_status_out<2>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
-    default: hipLaunchKernelGGL((qk_status_out<4>), grid, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, d->n_frames); break;
-    }
-    LAUNCHCHK();
-    return QLDPC_OK;
+    return for_each_gen(d, [&](const int *origin, const u64 *fin, int n_slots) -> int {
+        dim3 gs((unsigned)((n_slots + 255) / 256));
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_status_out<1>), gs, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, n_slots, origin, fin); break;
+        case 2: hipLaunchKernelGGL((qk_status_out<2>), gs, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, n_slots, origin, fin); break;
+        default: hipLaunchKernelGGL((qk_status_out<4>), gs, dim3(256), 0, d->stream, d->d_unsat, d->d_iters, d_iters, d_ok, n_slots, origin, fin); break;
+        }
+        LAUNCHCHK();
+        return (int)QLDPC_OK;
+    });
 }
 
 extern "C" int qldpc_fetch_post_dev(qldpc_decoder *d, float *d_post_out)
@@ -1138,6 +1079,11 @@ extern "C" int qldpc_fetch_post_dev(qldpc_decoder *d, float *d_post_out)
     if (d->engine == QLDPC_ENGINE_EDGES) {
         /* posterior of the last executed check pass, written frame-major directly (exact in fixed-iteration mode) */
         return edge_vn<QK_VN_POST>(d, 0, 0, 1, d_post_out, -1);
+    }
+    if (d->cur_gen != 0) {
+        qldpc_set_error("qldpc_fetch_post_dev: the run compacted its active frames (%d times), the messages of frames that converged earlier are gone; "
+                        "create the decoder with compact = 2 (or freeze_messages = 1) to read posteriors", d->compactions);
+        return QLDPC_EUNSUPPORTED;
     }
     const float *src;
     if (d->cfg.schedule == QLDPC_SCHED_FLOODING) {

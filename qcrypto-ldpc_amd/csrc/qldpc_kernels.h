@@ -153,6 +153,9 @@ template <int V> __device__ __forceinline__ void qk_stm(__half *p, const float (
         __builtin_nontemporal_store(t, reinterpret_cast<qk_u32x2 *>(p));
     }
 }
+/* one element (REMAP check passes: a lane's V frames come from V different rows of the old layout) */
+__device__ __forceinline__ float qk_ldm1(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float qk_ldm1(const __half *p) { return __half2float(__ushort_as_half(__builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p)))); }
 __device__ __forceinline__ void qk_put(float *p, float v) { *p = v; }
 __device__ __forceinline__ void qk_put(__half *p, float v) { *p = __float2half_rn(v); }
 
@@ -345,13 +348,18 @@ __device__ __forceinline__ float qk_first_v2c(float y, const __half *) { return 
  */
 /* FIRST: the check pass of iteration 0 in coded-LLR mode.  var_to_chk would hold (Y + 0) - 0 on every edge, so it is not read
  * (and the variable-node pass that would have written it is not run): the inputs are rebuilt from the coded LLRs of cn_var. */
-template <int V, int DCMAX, int FAM, typename MT, bool FIRST = false>
+/* REMAP: the check pass right after a compaction (qldpc_kernels_compact.h).  var_to_chk is still laid out for the old generation:
+ * frame (lane, j) of this group reads slot remap_src[g * FG + lane * V + j] of it (a per-lane base pointer; padding lanes read slot 0,
+ * their results are never looked at); chk_to_var is written in the new layout. */
+template <int V, int DCMAX, int FAM, typename MT, bool FIRST = false, bool REMAP = false>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__ v2c, MT *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                                           size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M,
-                                                          const int *__restrict__ cn_var = nullptr, int N = 0, qk_coded_llr coded = qk_coded_llr{})
+                                                          const int *__restrict__ cn_var = nullptr, int N = 0, qk_coded_llr coded = qk_coded_llr{},
+                                                          const int *__restrict__ remap_src = nullptr)
 {
+    static_assert(!(FIRST && REMAP), "no compaction before the first check pass");
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
     if (qk_group_done<V>(done, g)) return;
@@ -363,6 +371,15 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
     const bool any_frozen = qk_frozen<V>(done, g, lane, frozen) && freeze;
     const MT *vin = v2c + (size_t)g * group_stride + lane * V;
     MT *cout = c2v + (size_t)g * group_stride + lane * V;
+    const MT *vin_r[V];      /* REMAP only */
+    if constexpr (REMAP) {
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            int s = remap_src[(size_t)g * FG + lane * V + j];
+            s = s < 0 ? 0 : s;
+            vin_r[j] = v2c + (size_t)(s / FG) * group_stride + (s % FG);
+        }
+    }
 
     const int c = list[i];
     const int b = cn_ptr[c];
@@ -393,6 +410,13 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                     qk_coded_y<V>(x[k], coded, g, vid[k], N, lane, mg, nc);
 #pragma unroll
                     for (int j = 0; j < V; j++) x[k][j] = qk_first_v2c(x[k][j], vin);
+                }
+        } else if constexpr (REMAP) {
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) {
+#pragma unroll
+                    for (int j = 0; j < V; j++) x[k][j] = qk_ldm1(vin_r[j] + (size_t)slot[k] * FG);
                 }
         } else {
 #pragma unroll
@@ -438,6 +462,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                 qk_coded_y<V>(x, coded, g, cn_var[b + k], N, lane, mg, nc);
 #pragma unroll
                 for (int j = 0; j < V; j++) x[j] = qk_first_v2c(x[j], vin);
+            } else if constexpr (REMAP) {
+#pragma unroll
+                for (int j = 0; j < V; j++) x[j] = qk_ldm1(vin_r[j] + (size_t)cn_tr[b + k] * FG);
             } else qk_load<V>(x, vin + (size_t)cn_tr[b + k] * FG);
 #pragma unroll
             for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], qk_prep<FAM>(x[j]), rule);
@@ -451,6 +478,9 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                 qk_coded_y<V>(x, coded, g, cn_var[b + k], N, lane, mg, nc);
 #pragma unroll
                 for (int j = 0; j < V; j++) x[j] = qk_first_v2c(x[j], vin);
+            } else if constexpr (REMAP) {
+#pragma unroll
+                for (int j = 0; j < V; j++) x[j] = qk_ldm1(vin_r[j] + off);
             } else qk_load<V>(x, vin + off);
 #pragma unroll
             for (int j = 0; j < V; j++) o[j] = acc[j].out(qk_prep<FAM>(x[j]), rule);
@@ -775,16 +805,19 @@ __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask,
  * iteration counts; clears unsat for the next pass; counts groups still active. */
 template <int V>
 __global__ void qk_status(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
-                          int G, int syndrome_depth, int ite_done /* iterations executed so far */, int *__restrict__ active_groups)
+                          int G, int syndrome_depth, int ite_done /* iterations executed so far */, int *__restrict__ active_groups,
+                          unsigned long long *__restrict__ work)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.x;
     const int lane = threadIdx.x;   /* 64 threads */
-    bool all = true;
+    bool all = true, was_all = true;
+    int left = 0;
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const u64 u = unsat[(size_t)g * V + j];
         const u64 d = done[(size_t)g * V + j];
+        was_all = was_all && (d == ~0ull);
         const int f = g * FG + lane * V + j;
         const bool was_done = (d >> lane) & 1ull;
         const bool zero = !((u >> lane) & 1ull);
@@ -798,16 +831,20 @@ __global__ void qk_status(u64 *__restrict__ unsat, u64 *__restrict__ done, int *
         }
         const u64 nd = d | __ballot(now);
         all = all && (nd == ~0ull);
+        left += __popcll(~nd);
         if (lane == 0) { done[(size_t)g * V + j] = nd; unsat[(size_t)g * V + j] = 0; }
     }
-    if (lane == 0 && !all) atomicAdd(active_groups, 1);
+    /* active_groups[0] = groups with unconverged frames, [1] = those frames; work += 1 per group that ran this iteration */
+    if (lane == 0 && !all) { atomicAdd(active_groups, 1); atomicAdd(active_groups + 1, left); }
+    if (lane == 0 && !was_all) atomicAdd(work, 1ull);
     (void)G;
 }
 
 template <int V>
 __global__ void qk_status_init(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
-                               int n_frames, int n_ite)
+                               int n_frames, int n_ite, unsigned long long *__restrict__ work)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *work = 0ull;
     constexpr int FG = 64 * V;
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
@@ -822,16 +859,31 @@ __global__ void qk_status_init(u64 *__restrict__ unsat, u64 *__restrict__ done, 
 }
 
 /* ok[f] = !(unsat bit) after a syndrome pass over the hard ballots; iters copied out */
+/*
+ * Where slot f of a generation belongs in the caller's batch, or -1 if this generation does not hold the frame's result:
+ * origin == NULL: slot f is frame f (generation 0); final_mask (the generation's done words) != NULL: only frames that
+ * converged here count, the others moved on to the next generation at a compaction.
+ */
+template <int V> __device__ __forceinline__ int qk_result_frame(int f, int n_slots, const int *__restrict__ origin, const u64 *__restrict__ final_mask)
+{
+    constexpr int FG = 64 * V;
+    if (f >= n_slots) return -1;
+    const int g = f / FG, r = f % FG, lane = r / V, j = r % V;
+    if (final_mask && !((final_mask[(size_t)g * V + j] >> lane) & 1ull)) return -1;
+    return origin ? origin[f] : f;
+}
+
 template <int V>
 __global__ void qk_status_out(const u64 *__restrict__ unsat, const int *__restrict__ iters, int *__restrict__ out_iters,
-                              int *__restrict__ out_ok, int n_frames)
+                              int *__restrict__ out_ok, int n_slots, const int *__restrict__ origin, const u64 *__restrict__ final_mask)
 {
     constexpr int FG = 64 * V;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
+    const int o = qk_result_frame<V>(f, n_slots, origin, final_mask);
+    if (o < 0) return;
     const int g = f / FG, r = f % FG, lane = r / V, j = r % V;
-    if (out_iters) out_iters[f] = iters[f];
-    if (out_ok) out_ok[f] = !((unsat[(size_t)g * V + j] >> lane) & 1ull);
+    if (out_iters) out_iters[o] = iters[f];
+    if (out_ok) out_ok[o] = !((unsat[(size_t)g * V + j] >> lane) & 1ull);
 }
 
 /* ------------------------------------------------------------------ load / fetch ------------- */
@@ -926,7 +978,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
 }
 
 /* per-frame constants of the coded-LLR form: fmag[f] = |LLR| (1 for padding frames), fnch[f] = shortening length (N = none) */
-__global__ __launch_bounds__(256) void qk_load_frame_consts(const float *__restrict__ llr_mag, const int *__restrict__ n_channel,
+static __global__ __launch_bounds__(256) void qk_load_frame_consts(const float *__restrict__ llr_mag, const int *__restrict__ n_channel,
                                                             float *__restrict__ fmag, int *__restrict__ fnch, int n_frames, int total, int N)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -960,7 +1012,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_syndrome(const uint32_t *_
 }
 
 /* s = H x for packed words x[n_frames][Wn] -> s[n_frames][Wm] (Alice's side of the syndrome form) */
-__global__ __launch_bounds__(256) void qk_syndrome_of_bits(const uint32_t *__restrict__ x, const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
+static __global__ __launch_bounds__(256) void qk_syndrome_of_bits(const uint32_t *__restrict__ x, const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
                                                            uint32_t *__restrict__ s, int M, int Wn, int Wm)
 {
     const int f = blockIdx.y;
@@ -981,12 +1033,15 @@ __global__ __launch_bounds__(256) void qk_syndrome_of_bits(const uint32_t *__res
 /* hard ballots -> packed MSB-first words out[n_frames][W] */
 template <int V>
 __global__ __launch_bounds__(QK_THREADS) void qk_fetch_packed(const u64 *__restrict__ hard, uint32_t *__restrict__ out,
-                                                              int N, int W, int n_frames)
+                                                              int N, int W, int n_slots, const int *__restrict__ origin, const u64 *__restrict__ final_mask)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int dest[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) dest[j] = qk_result_frame<V>(g * FG + lane * V + j, n_slots, origin, final_mask);
     for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
         uint32_t word[V];
 #pragma unroll
@@ -998,26 +1053,25 @@ __global__ __launch_bounds__(QK_THREADS) void qk_fetch_packed(const u64 *__restr
             for (int j = 0; j < V; j++) word[j] |= (uint32_t)((hard[((size_t)g * N + v) * V + j] >> lane) & 1ull) << (31 - b);
         }
 #pragma unroll
-        for (int j = 0; j < V; j++) {
-            const int f = g * FG + lane * V + j;
-            if (f < n_frames) out[(size_t)f * W + w] = word[j];
-        }
+        for (int j = 0; j < V; j++)
+            if (dest[j] >= 0) out[(size_t)dest[j] * W + w] = word[j];
     }
 }
 
 /* hard ballots -> V_K[n_frames][K] ints at info_bits_pos (decode_siho's output layout) */
 template <int V>
 __global__ __launch_bounds__(256) void qk_fetch_info(const u64 *__restrict__ hard, const int *__restrict__ info_pos,
-                                                     int *__restrict__ out, int N, int K, int n_frames)
+                                                     int *__restrict__ out, int N, int K, int n_slots, const int *__restrict__ origin, const u64 *__restrict__ final_mask)
 {
     constexpr int FG = 64 * V;
     const int f = blockIdx.y;
+    const int o = qk_result_frame<V>(f, n_slots, origin, final_mask);
+    if (o < 0) return;
     const int g = f / FG, r = f % FG, lane = r / V, j = r % V;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) {
         const int v = info_pos[i];
-        out[(size_t)f * K + i] = (int)((hard[((size_t)g * N + v) * V + j] >> lane) & 1ull);
+        out[(size_t)o * K + i] = (int)((hard[((size_t)g * N + v) * V + j] >> lane) & 1ull);
     }
-    (void)n_frames;
 }
 
 #endif /* QLDPC_KERNELS_H */

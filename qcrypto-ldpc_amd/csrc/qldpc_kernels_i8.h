@@ -106,14 +106,18 @@ struct qi_acc {
 
 /* FIRST: the check pass of iteration 0 reads the quantised channel LLRs of its VNs (what the first variable-node pass would
  * have copied into var_to_chk: |Yq| <= 127 needs no clamp), so that pass is not run */
-template <int DCMAX, bool FIRST = false>
+/* REMAP: the check pass right after a compaction (see qk_cn_flood): each of the lane's four frames reads its byte from the slot
+ * of the old layout it came from */
+template <int DCMAX, bool FIRST = false, bool REMAP = false>
 __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__restrict__ v2c, uint32_t *__restrict__ c2v,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                                           size_t group_stride /* dwords */, const u64 *__restrict__ done, qi_rule rule,
                                                           const u64 *__restrict__ synd, int M,
-                                                          const uint32_t *__restrict__ llr8 = nullptr, const int *__restrict__ cn_var = nullptr, int N = 0)
+                                                          const uint32_t *__restrict__ llr8 = nullptr, const int *__restrict__ cn_var = nullptr, int N = 0,
+                                                          const int *__restrict__ remap_src = nullptr)
 {
+    static_assert(!(FIRST && REMAP), "no compaction before the first check pass");
     const int g = blockIdx.y;
     if (qk_group_done<QI_V>(done, g)) return;
     const int lane = threadIdx.x & 63;
@@ -122,6 +126,21 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
     if (i >= n_list) return;
     const uint32_t *vin = v2c + (size_t)g * group_stride + lane;
     uint32_t *cout = c2v + (size_t)g * group_stride + lane;
+    const uint8_t *vin_r[QI_V];      /* REMAP only */
+    if constexpr (REMAP) {
+#pragma unroll
+        for (int j = 0; j < QI_V; j++) {
+            int s = remap_src[(size_t)g * QI_FG + lane * QI_V + j];
+            s = s < 0 ? 0 : s;
+            vin_r[j] = reinterpret_cast<const uint8_t *>(v2c + (size_t)(s / QI_FG) * group_stride) + (s % QI_FG);
+        }
+    }
+    auto remap_word = [&](size_t slot) {      /* the four bytes of this lane's dword, each from its own source row */
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < QI_V; j++) w |= (uint32_t)__builtin_nontemporal_load(vin_r[j] + slot * QI_FG) << (8 * j);
+        return w;
+    };
     const int c = list[i];
     const int b = cn_ptr[c];
     const int deg = cn_ptr[c + 1] - b;
@@ -146,6 +165,10 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
 #pragma unroll
             for (int k = 0; k < DCMAX; k++)
                 if (k < deg) w[k] = llr8[((size_t)g * N + vid[k]) * 64 + lane];
+        } else if constexpr (REMAP) {
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++)
+                if (k < deg) w[k] = remap_word((size_t)slot[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < DCMAX; k++)
@@ -162,14 +185,14 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
     } else {
         for (int k = 0; k < deg; k++) {
             qi_s2 xl, xh;
-            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : vin[(size_t)cn_tr[b + k] * 64], xl, xh);
+            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : (REMAP ? remap_word((size_t)cn_tr[b + k]) : vin[(size_t)cn_tr[b + k] * 64]), xl, xh);
             lo.in(xl); hi.in(xh);
         }
         lo.finish(rule); hi.finish(rule);
         for (int k = 0; k < deg; k++) {
             const size_t off = (size_t)cn_tr[b + k] * 64;
             qi_s2 xl, xh;
-            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : vin[off], xl, xh);
+            qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : (REMAP ? remap_word((size_t)cn_tr[b + k]) : vin[off]), xl, xh);
             cout[off] = qi_pack(lo.out(xl), hi.out(xh));
         }
     }
@@ -397,7 +420,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_layer(uint32_t *__restrict__
 }
 
 /* ballots of the 8-bit posterior array: sgn = hard = (post < 0); converged frames keep theirs */
-__global__ __launch_bounds__(QK_THREADS) void qi_post_ballots(const uint32_t *__restrict__ post8, u64 *__restrict__ sgn, u64 *__restrict__ hard,
+static __global__ __launch_bounds__(QK_THREADS) void qi_post_ballots(const uint32_t *__restrict__ post8, u64 *__restrict__ sgn, u64 *__restrict__ hard,
                                                               int N, const u64 *__restrict__ done)
 {
     const int g = blockIdx.y;
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_post_ballots(const uint32_t *__
 }
 
 /* [G][N][256] int8 -> [G][N][256] f32 (posterior read-back) */
-__global__ __launch_bounds__(256) void qi_post_to_f32(const uint32_t *__restrict__ post8, float *__restrict__ dst, size_t n_dwords)
+static __global__ __launch_bounds__(256) void qi_post_to_f32(const uint32_t *__restrict__ post8, float *__restrict__ dst, size_t n_dwords)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t w = post8[i];
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(256) void qi_post_to_f32(const uint32_t *__restrict
  * between): packed sifted-key words + per-frame |LLR| -> llr8[G][N][256], Yq = +-quant(|LLR|) at channel VNs, +-quant(23.03) at
  * pinned VNs (and at channel VNs past the frame's shortening length), 0 at punctured VNs; padding frames get quant(1).
  */
-__global__ __launch_bounds__(QK_THREADS) void qi_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag,
+static __global__ __launch_bounds__(QK_THREADS) void qi_load_bits(const uint32_t *__restrict__ bits, const float *__restrict__ llr_mag,
                                                            const uint8_t *__restrict__ vn_class, uint32_t *__restrict__ llr8,
                                                            int N, int W, int n_frames, const int *__restrict__ n_channel, float scale)
 {
@@ -472,7 +495,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_load_bits(const uint32_t *__res
 }
 
 /* channel LLRs [G][N][256] f32 -> [G][N][256] int8, four frames of a lane per dword */
-__global__ __launch_bounds__(256) void qi_quant_llr(const float *__restrict__ llr, uint32_t *__restrict__ llr8, size_t n_dwords, float scale)
+static __global__ __launch_bounds__(256) void qi_quant_llr(const float *__restrict__ llr, uint32_t *__restrict__ llr8, size_t n_dwords, float scale)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) {
         const qk_f32x4 v = *reinterpret_cast<const qk_f32x4 *>(llr + i * 4);

@@ -322,7 +322,8 @@ def test_default_mode_freezes_decisions_not_messages(q, O, torch, peg, sched, V)
         inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
         og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
     ref = O.decode(og, llr, "NMS", 0.75, 25, sched, True, 1, n_threads=8)
-    dec = q.Decoder(code, 1008, 25, rule="NMS", rule_param=0.75, n_frames=F, schedule=sched, frames_per_lane=V, engine="frames")
+    # compact="off": posteriors are read back below, which a run that compacted its active frames refuses (tests/test_compaction_gpu.py)
+    dec = q.Decoder(code, 1008, 25, rule="NMS", rule_param=0.75, n_frames=F, schedule=sched, frames_per_lane=V, engine="frames", compact="off")
     hard, it, ok, post = staged(q, torch, dec, llr)
     assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
     ran_all = it == dec.last_run_iterations            # frames that were never frozen keep exact posteriors

@@ -35,6 +35,9 @@ for synd in (True, False):
     tot = sum(s["total_ms"] for s in st)
     print("enable_syndrome=%s: launched %d iterations, avg %.2f, max %d; kernel time %.2f ms" % (synd, dec.last_run_iterations, it.float().mean().item(), it.max().item(), tot))
     hist = np.bincount(it.cpu().numpy(), minlength=20)
+    if synd:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.save(os.path.join(ROOT, "gpurun_out", "iters_%d.npy" % F), it.cpu().numpy())
     print("  iteration histogram:", {i: int(c) for i, c in enumerate(hist) if c})
     g = it.cpu().numpy().reshape(-1, 64).max(axis=1)
     print("  per-64-frame-group max: mean %.2f  -> ideal group-granular work %.1f%% of launched" % (g.mean(), 100 * g.mean() / dec.last_run_iterations))
