@@ -231,7 +231,10 @@ def main():
     cn_bytes = cn["alg_bytes"] / cn["launches"]
     achieved = cn_bytes / cn_avg_s / 1e9
     vn_achieved = (vn["alg_bytes"] / vn["launches"]) / (vn["total_ms"] / vn["launches"] * 1e-3) / 1e9
-    step_bytes = sum(s["alg_bytes"] for s in kstats.values()) / args.steps
+    vn_moved = (vn["moved_bytes"] / vn["launches"]) / (vn["total_ms"] / vn["launches"] * 1e-3) / 1e9
+    distinct = {id(s): s for s in kstats.values()}.values()       # hlayered aliases cn / vn to the layer pass: count it once
+    step_bytes = sum(s["alg_bytes"] for s in distinct) / args.steps
+    step_moved = sum(s["moved_bytes"] for s in distinct) / args.steps
     fixed_iters = dec.last_run_iterations
     del dec
     torch.cuda.empty_cache()
@@ -344,10 +347,15 @@ def main():
                 "bound": "hbm", "kernel": "qk_cn_flood (check-node update)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "alg_bytes_per_launch": cn_bytes, "avg_launch_ms": cn_avg_s * 1e3, "launches": cn["launches"],
-                "vn_update": {"achieved": vn_achieved, "frac": vn_achieved / HBM_PEAK_GBS,
+                # "achieved" prices the SURVEY 8d algorithmic bytes (an N x 4 B LLR array per pass); "moved" the bytes the pass really
+                # fetches with coded LLRs (N / 8 B of received-bit ballots per frame)
+                "vn_update": {"achieved": vn_achieved, "frac": vn_achieved / HBM_PEAK_GBS, "moved": vn_moved, "moved_frac": vn_moved / HBM_PEAK_GBS,
+                              "alg_bytes_per_pass": vn["alg_bytes"] / vn["launches"], "moved_bytes_per_pass": vn["moved_bytes"] / vn["launches"],
                               "avg_pass_ms": vn["total_ms"] / vn["launches"], "passes": vn["launches"]},
                 "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
-                               "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                               "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                               "moved_bytes": step_moved, "moved": step_moved / (dt / args.steps) / 1e9,
+                               "moved_frac": step_moved / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             },
             "cpu_baseline": cpu,
             "early_exit": early,

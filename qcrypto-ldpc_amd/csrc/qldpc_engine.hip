@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,7 +96,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->cn_buckets) (void)hipFree(b.d_list);
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
-    (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos);
+    (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
@@ -148,6 +149,14 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     HIPCHK(hipMemcpy(d->d_cn_tr, code->transpose, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_cn_var, code->cn_var, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_vn_ptr, code->vn_ptr, sizeof(int) * ((size_t)d->N + 1), hipMemcpyHostToDevice));
+    {   /* check -> VN table transposed to [edge position][check] for the syndrome pass (qk_syndrome) */
+        d->max_dc = code->max_dc;
+        std::vector<int> t((size_t)std::max(1, code->max_dc) * d->M, -1);
+        for (int c = 0; c < d->M; c++)
+            for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) t[(size_t)(k - code->cn_ptr[c]) * d->M + c] = code->cn_var[k];
+        if ((rc = dev_alloc(d, &d->d_cn_var_t, t.size()))) return rc;
+        HIPCHK(hipMemcpy(d->d_cn_var_t, t.data(), sizeof(int) * t.size(), hipMemcpyHostToDevice));
+    }
     {
         std::vector<int> pos((size_t)K);
         for (int i = 0; i < K; i++) {
@@ -256,9 +265,12 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if ((rc = dev_alloc(d, &d->d_done, G * V))) return rc;
     if ((rc = dev_alloc(d, &d->d_depth, G * FG))) return rc;
     if ((rc = dev_alloc(d, &d->d_iters, G * FG))) return rc;
-    if ((rc = dev_alloc(d, &d->d_active, 2))) return rc;
+    if ((rc = dev_alloc(d, &d->d_active, 4))) return rc;
+    HIPCHK(hipMemset(d->d_active, 0, 4 * sizeof(int)));
     if ((rc = dev_alloc(d, &d->d_work, 1))) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_active, 2 * sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&d->h_active, 4 * sizeof(int), hipHostMallocMapped));
+    memset(d->h_active, 0, 4 * sizeof(int));
+    HIPCHK(hipHostGetDevicePointer((void **)&d->h_active_dev, d->h_active, 0));
     /* active-frame compaction (early exit, flooding, messages not frozen): reserved[0] = 0 auto (batches of >= 4 groups), 1 always, 2 never */
     d->G0 = d->G;
     d->compact_mode = cfg->compact;
@@ -464,9 +476,10 @@ template <int V>
 static int synd_pass(qldpc_decoder *d, const u64 *mask, int skip_done)
 {
     prof_scope ps(d, KS_SYND, (double)d->E * 8.0 * d->G * V);
-    int bx = std::max(1, std::min((d->M + 255) / 256, 4096 / std::max(1, d->G)));
-    hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)bx, (unsigned)d->G), dim3(256), 0, d->stream, mask, d->d_cn_ptr, d->d_cn_var, d->M, d->N,
-                       d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr);
+    const int bx = std::max(1, std::min((d->M + 255) / 256, 4096 / std::max(1, d->G)));
+    const int g8 = (d->G + 7) / 8 * 8;      /* groups rounded up to the XCD count: see qk_syndrome */
+    hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)(g8 * bx)), dim3(256), 0, d->stream, mask, d->d_cn_var_t, d->max_dc, d->M, d->N,
+                       d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr, d->G, bx);
     LAUNCHCHK();
     return QLDPC_OK;
 }
@@ -474,19 +487,31 @@ template <int V>
 static int status_pass(qldpc_decoder *d, int ite_done)
 {
     prof_scope ps(d, KS_STATUS, 0.0);
-    HIPCHK(hipMemsetAsync(d->d_active, 0, 2 * sizeof(int), d->stream));
     hipLaunchKernelGGL((qk_status<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->G,
-                       d->cfg.syndrome_depth, ite_done, d->d_active, d->d_work);
+                       d->cfg.syndrome_depth, ite_done, d->d_active, d->d_work, (volatile int *)d->h_active_dev, ++d->poll_seq);
     LAUNCHCHK();
     return QLDPC_OK;
 }
-/* blocking: how many groups still have unconverged frames, and how many frames those are */
+/* blocking: how many groups still have unconverged frames after the status pass launched last, and how many frames those are.
+ * The kernel writes the counts and then its sequence number into mapped pinned memory; the host spins on the sequence word. */
 static int poll_active(qldpc_decoder *d, int *active, int *active_frames = nullptr)
 {
-    HIPCHK(hipMemcpyAsync(d->h_active, d->d_active, 2 * sizeof(int), hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    *active = d->h_active[0];
-    if (active_frames) *active_frames = d->h_active[1];
+    int *h = d->h_active;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&h[2], __ATOMIC_ACQUIRE) != d->poll_seq) {
+        if ((++spins & 0xfffu) == 0) {
+            hipError_t e = hipStreamQuery(d->stream);      /* a failed launch / device fault must not leave the host spinning */
+            if (e != hipSuccess && e != hipErrorNotReady) { qldpc_set_error("early-exit poll: %s", hipGetErrorString(e)); return QLDPC_EHIP; }
+            if (e == hipSuccess && __atomic_load_n(&h[2], __ATOMIC_ACQUIRE) != d->poll_seq) {
+                /* the stream has drained: the report is on its way through the host's memory system, or was never written */
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) { qldpc_set_error("early-exit poll: status report never arrived"); return QLDPC_EHIP; }
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { qldpc_set_error("early-exit poll: timed out"); return QLDPC_EHIP; }
+        }
+    }
+    *active = h[0];
+    if (active_frames) *active_frames = h[1];
     return QLDPC_OK;
 }
 
@@ -647,7 +672,7 @@ static int run_v(qldpc_decoder *d)
     d->live_lanes = 0;
     {
         prof_scope ps(d, KS_STATUS, 0.0);
-        hipLaunchKernelGGL((qk_status_init<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->n_frames, d->cfg.n_ite, d->d_work);
+        hipLaunchKernelGGL((qk_status_init<V>), dim3((unsigned)d->G), dim3(64), 0, d->stream, d->d_unsat, d->d_done, d->d_depth, d->d_iters, d->n_frames, d->cfg.n_ite, d->d_work, d->d_active);
         LAUNCHCHK();
     }
     int rc = d->cfg.schedule == QLDPC_SCHED_FLOODING ? run_flooding<V>(d) : run_layered<V>(d);

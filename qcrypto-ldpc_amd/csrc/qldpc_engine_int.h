@@ -55,6 +55,7 @@ struct qldpc_decoder {
     hipStream_t stream;
     /* graph on device */
     int *d_cn_ptr, *d_cn_tr, *d_cn_var, *d_vn_ptr, *d_info_pos;
+    int *d_cn_var_t, max_dc;         /* cn_var transposed to [edge position][check], -1 padded (syndrome pass) */
     std::vector<bucket> cn_buckets, vn_buckets;
     std::vector<std::vector<bucket>> layer_buckets;   /* per layer */
     int n_layers;
@@ -63,7 +64,8 @@ struct qldpc_decoder {
     float *d_post;                   /* lazily allocated by fetch_post */
     u64 *d_sgn, *d_hard, *d_unsat, *d_done;
     int *d_depth, *d_iters, *d_active;   /* d_active[0] = groups, [1] = frames still unconverged after the last status pass */
-    int *h_active;                   /* pinned, 2 ints */
+    int *h_active, *h_active_dev;    /* mapped pinned memory {groups, frames, sequence number} and its device address: qk_status reports, the host spins */
+    int poll_seq;
     unsigned long long *d_work;      /* group-iterations executed in the current run (qk_status) */
     /* active-frame compaction: generations of the per-frame state; the d_* pointers above and G are the CURRENT generation's */
     int G0;

@@ -754,41 +754,44 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
 
 /* ------------------------------------------------------------------ syndrome + status -------- */
 
-/* check_syndrome_soft for FG frames at once: XOR the VN ballots of each check, OR over checks. */
+/*
+ * check_syndrome_soft for FG frames at once: XOR the VN ballots of each check, OR over checks.
+ * 1-D grid of 8 * ceil(G / 8) * bx workgroups.  Workgroups are dealt round-robin to the 8 XCDs, whose L2s are not coherent with
+ * each other: the ballots the variable-node pass just wrote come in over the fabric, so ALL workgroups of a group are placed on ONE
+ * XCD (g = id % 8 + 8 * (id / 8 / bx)) and its 8 N bytes of ballots cross the fabric once instead of eight times (measured on the
+ * config-2 batch: 68 -> 58 us per pass; what remains is the tag-lookup rate of 64-address gathers, not bytes).
+ */
 template <int V>
-__global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_ptr,
-                                                   const int *__restrict__ cn_var, int M, int N,
-                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done, const u64 *__restrict__ synd)
+__global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_var_t, int max_dc, int M, int N,
+                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done, const u64 *__restrict__ synd, int G, int bx)
 {
-    const int g = blockIdx.y;
+    const int id = blockIdx.x;
+    const int g = (id & 7) + 8 * ((id >> 3) / bx);
+    const int chunk = (id >> 3) % bx;
+    if (g >= G) return;
     if (skip_done && qk_group_done<V>(done, g)) return;
     const u64 *mg = mask + (size_t)g * N * V;
     u64 acc[V];
 #pragma unroll
     for (int j = 0; j < V; j++) acc[j] = 0;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < M; c += gridDim.x * blockDim.x) {
+    for (int c = chunk * blockDim.x + threadIdx.x; c < M; c += bx * blockDim.x) {
         u64 s[V];
 #pragma unroll
         for (int j = 0; j < V; j++) s[j] = synd ? synd[((size_t)g * M + c) * V + j] : 0ull;      /* H x must equal the target syndrome */
-        /* six independent index loads, then six independent ballot gathers per trip (the ballot array of a group sits in L2):
-         * the one-edge-at-a-time loop was a chain of dependent loads */
-        int k = cn_ptr[c];
-        const int e = cn_ptr[c + 1];
-        for (; k + 6 <= e; k += 6) {
-            int v[6];
+        /* cn_var_t is the check -> VN table transposed to [edge position][check] (-1 past a check's degree): consecutive lanes read
+         * consecutive ints, ten independent index loads and then ten independent ballot gathers per trip */
+        constexpr int B = 10;
+        for (int t0 = 0; t0 < max_dc; t0 += B) {
+            int v[B];
 #pragma unroll
-            for (int t = 0; t < 6; t++) v[t] = cn_var[k + t];
+            for (int t = 0; t < B; t++) v[t] = (t0 + t < max_dc) ? cn_var_t[(size_t)(t0 + t) * M + c] : -1;
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const u64 *p = mg + (size_t)v[t] * V;
+            for (int t = 0; t < B; t++)
+                if (v[t] >= 0) {
+                    const u64 *p = mg + (size_t)v[t] * V;
 #pragma unroll
-                for (int j = 0; j < V; j++) s[j] ^= p[j];
-            }
-        }
-        for (; k < e; k++) {
-            const u64 *p = mg + (size_t)cn_var[k] * V;
-#pragma unroll
-            for (int j = 0; j < V; j++) s[j] ^= p[j];
+                    for (int j = 0; j < V; j++) s[j] ^= p[j];
+                }
         }
 #pragma unroll
         for (int j = 0; j < V; j++) acc[j] |= s[j];
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask,
 template <int V>
 __global__ void qk_status(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
                           int G, int syndrome_depth, int ite_done /* iterations executed so far */, int *__restrict__ active_groups,
-                          unsigned long long *__restrict__ work)
+                          unsigned long long *__restrict__ work, volatile int *__restrict__ host_report, int seq)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.x;
@@ -837,14 +840,25 @@ __global__ void qk_status(u64 *__restrict__ unsat, u64 *__restrict__ done, int *
     /* active_groups[0] = groups with unconverged frames, [1] = those frames; work += 1 per group that ran this iteration */
     if (lane == 0 && !all) { atomicAdd(active_groups, 1); atomicAdd(active_groups + 1, left); }
     if (lane == 0 && !was_all) atomicAdd(work, 1ull);
-    (void)G;
+    /* the workgroup that finishes last hands the two counts to the host through mapped pinned memory (the host spins on the sequence
+     * word: no copy, no stream synchronisation in the early-exit loop) and clears them for the next pass */
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(active_groups + 2, 1) == G - 1) {
+            const int a0 = atomicExch(active_groups, 0), a1 = atomicExch(active_groups + 1, 0);
+            atomicExch(active_groups + 2, 0);
+            host_report[0] = a0; host_report[1] = a1;
+            __threadfence_system();
+            __hip_atomic_store(const_cast<int *>(host_report) + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 template <int V>
 __global__ void qk_status_init(u64 *__restrict__ unsat, u64 *__restrict__ done, int *__restrict__ depth, int *__restrict__ iters,
-                               int n_frames, int n_ite, unsigned long long *__restrict__ work)
+                               int n_frames, int n_ite, unsigned long long *__restrict__ work, int *__restrict__ active_groups)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *work = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *work = 0ull; active_groups[0] = 0; active_groups[1] = 0; active_groups[2] = 0; }
     constexpr int FG = 64 * V;
     const int g = blockIdx.x;
     const int lane = threadIdx.x;

@@ -14,6 +14,8 @@ import bench  # noqa: E402
 
 q = _qldpc_loader.load()
 F = int(os.environ.get("FRAMES", "4096"))
+DTYPE = os.environ.get("DTYPE", "f32")
+COMPACT = os.environ.get("COMPACT", "auto")
 dev = torch.device("cuda", 0)
 code = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
 enc = q.Encoder(code, "IRA")
@@ -22,14 +24,19 @@ mag = torch.full((F,), q.bsc_llr(0.02), dtype=torch.float32, device=dev)
 cls = torch.zeros(code.N, dtype=torch.uint8, device=dev)
 cls[enc.K:] = 1
 for synd in (True, False):
-    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, enable_syndrome=synd, n_frames=F)
+    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, enable_syndrome=synd, n_frames=F, msg_dtype=DTYPE, compact=COMPACT)
     dec.set_stream(torch.cuda.current_stream())
-    for rep in range(2):
-        dec.profile(rep == 1)
+    import time
+    for rep in range(4):
+        dec.profile(rep == 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         dec.load_bits(rx, mag, cls)
         dec.run()
         out = dec.fetch_packed()
         torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+    print("wall of the step before the profiled one: %.3f ms (%s)" % (wall, dec.last_run_stats()))
     it, ok = dec.fetch_status()
     st = dec.profile_read()
     tot = sum(s["total_ms"] for s in st)
