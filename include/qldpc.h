@@ -223,6 +223,13 @@ int qldpc_load_bits_short_dev(qldpc_decoder *dec, const uint32_t *d_bits, const 
  * any H (no encoder needed); not an AFF3CT configuration, so it is checked against the oracle's own coset mode.
  */
 int qldpc_load_syndrome_dev(qldpc_decoder *dec, const uint32_t *d_synd_bits, int n_frames);
+/*
+ * Per-frame puncturing (BS/src/main.cpp:359-362, the harness's `LLRs[pattern[i]] = 0` with a pattern of its own for every frame):
+ * d_erase_bits[n_frames][ceil(N/32)] packed MSB-first, a set bit makes that VN of that frame an erasure (channel LLR 0) whatever
+ * its class in d_vn_class.  Lets blocks punctured to different efficiencies share one code and one launch.  Call after
+ * qldpc_load_bits_* / qldpc_load_llr_dev for the frames just loaded; the next load clears it.
+ */
+int qldpc_load_erasures_dev(qldpc_decoder *dec, const uint32_t *d_erase_bits, int n_frames);
 /* s = H x for packed words d_bits[n_frames][ceil(N/32)] -> d_synd_bits[n_frames][ceil(M/32)] (Alice's side). */
 int qldpc_syndrome_dev(qldpc_decoder *dec, const uint32_t *d_bits, uint32_t *d_synd_bits, int n_frames);
 /* run the BP iterations on what was loaded. */
@@ -281,10 +288,13 @@ int qldpc_encode_packed_dev(qldpc_encoder *enc, const uint32_t *d_info, uint32_t
  * and :420-423 call into this.  Buffers are the daemon's own: ProcessBlock.mainBufPtr words,
  * MSB-first (helpers.h:65-70), `workbits` valid bits (helpers.c:31-69), QBER = localError.
  *
- * Per block: rate = largest table rate <= min_cr(qber, efficiency) (BS/src/main.cpp:29,235-266);
- * code = IRA with K = workbits rounded up to `key_quantum` (extra info VNs are shortened: known 0)
- * and M = round(K (1-R)/R) parity VNs; Alice sends the M parity bits + CRC-32 of her key; Bob pins
- * them (+-23.03), decodes and verifies.  Leak = M + 32 bits.
+ * Per block (qldpc_recon_plan): the QBER estimate is clamped to [0.001, 0.25]; target rate R* = min(min_cr(qber, efficiency),
+ * capacity - rate_gap (65536/K)^0.4) (BS/src/main.cpp:29); table rate = largest entry <= R* (:235-266); code = IRA MOTHER code with K a multiple of
+ * `mother_step` (blocks above `mother_max` bits: K = workbits rounded up to `key_quantum`) and M = round(K (1-R)/R) parity VNs, the
+ * information VNs past the block's length are shortened (known 0, pinned per frame); of the M parity bits only
+ * d = ceil(workbits (1/R* - 1)) are disclosed and the other M - d are punctured (BS/src/main.cpp:34,305-311,359-362:
+ * parity_bits_to_punct, LLR 0), evenly spaced along the accumulator.  Alice sends the d parity bits + CRC-32 of her key; Bob pins
+ * them (+-23.03), erases the punctured ones, decodes and verifies.  Leak = d + 32 bits.
  */
 typedef struct qldpc_recon qldpc_recon;
 
@@ -301,24 +311,36 @@ typedef struct qldpc_recon_cfg {
     uint64_t seed;         /* IRA construction seed shared by both sides (7)                     */
     int schedule;          /* qldpc_schedule of Bob's decoder: FLOODING (default) or HLAYERED (about half the
                               iterations; batches only -- the one-block edge engine is flooding)           */
-    int reserved[7];
+    int mother_step;       /* 8192: blocks of up to mother_max bits use mother codes whose K is a multiple of this (a block
+                              is shortened to its length per frame), so a handful of codes serve every block; 0 = a code per size */
+    int mother_max;        /* 65536 */
+    float rate_gap;        /* the effective rate stays rate_gap (65536 / K)^0.4 below the BSC capacity 1 - h(q); 0 = by rule
+                              (0.035 SPA / LSPA, 0.05 min-sum family): measured FER 0 over QBER 0.3 .. 8 %, DESIGN.md     */
+    int puncture;          /* 1 (default): puncture parity VNs down to the target efficiency; 0 / 2: disclose all M    */
+    int preload;           /* 1: build every (mother size, rate) entry in qldpc_recon_create -- no code construction and no
+                              device allocation afterwards for blocks of up to mother_max bits                          */
+    int reserved[2];       /* must be zero */
 } qldpc_recon_cfg;
 
 /* Travels in the parity packet (all fields uint32, little-endian like every ecd2 header). */
 typedef struct qldpc_recon_msg {
     uint32_t rate_index;   /* index into the rate table                                          */
     uint32_t key_bits;     /* workbits                                                           */
-    uint32_t code_k;       /* info VNs (key_bits rounded up to key_quantum)                      */
-    uint32_t code_m;       /* parity VNs = disclosed bits                                        */
+    uint32_t code_k;       /* info VNs of the (mother) code, >= key_bits                         */
+    uint32_t code_m;       /* parity VNs of the code                                             */
     uint32_t crc32;        /* CRC-32 (IEEE) of Alice's key words, tail bits masked               */
+    uint32_t n_punct;      /* parity VNs punctured: code_m - n_punct bits are disclosed          */
 } qldpc_recon_msg;
 
 void qldpc_recon_cfg_default(qldpc_recon_cfg *cfg);
 int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out);
 void qldpc_recon_free(qldpc_recon *r);
-/* Rate choice and code dimensions for a block; fills rate_index, key_bits, code_k, code_m. */
+/* Rate choice, code dimensions and puncturing for a block; fills everything but crc32.  qber in [0, 0.5) (0 is clamped). */
 int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon_msg *msg);
-/* Alice: parity words (ceil(code_m/32), MSB-first) + message header for her key. */
+int qldpc_recon_parity_words(const qldpc_recon_msg *msg);    /* words of disclosed parity a message carries: ceil((code_m - n_punct)/32) */
+int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg);     /* code_m - n_punct + 32 (CRC)                                             */
+long qldpc_recon_entries_created(const qldpc_recon *r);      /* (code, encoder, decoder) sets built so far: constant after a preload   */
+/* Alice: the disclosed parity bits (qldpc_recon_parity_words(msg_out) words, MSB-first, in position order) + message header. */
 int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber,
                        qldpc_recon_msg *msg_out, uint32_t *parity_words, int parity_cap_words);
 /* Bob: corrects key_words in place.  QLDPC_OK = decoded and CRC verified; QLDPC_EDECODE = failed,
@@ -326,7 +348,8 @@ int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, 
 int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float qber, const qldpc_recon_msg *msg,
                        const uint32_t *parity_words, int *corrected_bits, int *leaked_bits, int *iterations);
 /* Bob, n blocks that share one plan (same key_bits / rate / code dims) in one launch.
- * key_words[n][ceil(key_bits/32)], parity_words[n][ceil(code_m/32)], status[n] = QLDPC_OK / QLDPC_EDECODE. */
+ * key_words[n][ceil(key_bits/32)], parity_words[n][ceil(code_m/32)] (row i holds qldpc_recon_parity_words(&msgs[i]) words),
+ * status[n] = QLDPC_OK / QLDPC_EDECODE / QLDPC_ESIZE (that block's header does not match it). */
 /* Alice's side for many blocks of any mix of lengths / plans in one call: every msgs[i] is planned and filled as by
  * qldpc_recon_encode, blocks are grouped by plan and encoded in launches of up to max_blocks frames. */
 int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *const *key_words, const int *key_bits, const float *qber,

@@ -105,7 +105,9 @@ _sig("qldpc_decoder_device_bytes", C.c_size_t, [_vp])
 _sig("qldpc_decode_siho", C.c_int, [_vp, _fp, _ip, C.c_int])
 _sig("qldpc_load_llr_dev", C.c_int, [_vp, _vp, C.c_int])
 _sig("qldpc_load_bits_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_int])
+_sig("qldpc_load_bits_short_dev", C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int])
 _sig("qldpc_load_syndrome_dev", C.c_int, [_vp, _vp, C.c_int])
+_sig("qldpc_load_erasures_dev", C.c_int, [_vp, _vp, C.c_int])
 _sig("qldpc_syndrome_dev", C.c_int, [_vp, _vp, _vp, C.c_int])
 _sig("qldpc_run", C.c_int, [_vp])
 _sig("qldpc_fetch_packed_dev", C.c_int, [_vp, _vp])
@@ -333,7 +335,9 @@ class Decoder:
         self.n_frames = llr.shape[0]
         _chk(_L.qldpc_load_llr_dev(self._h, _vp(llr.data_ptr()), llr.shape[0]), "load_llr")
 
-    def load_bits(self, bits, llr_mag, vn_class=None):
+    def load_bits(self, bits, llr_mag, vn_class=None, n_channel=None):
+        """QKD frame formation on the device; n_channel[f] (int32, optional): channel VNs at index >= n_channel[f] are known
+        (shortened) bits of frame f"""
         torch = _torch()
         W = (self.N + 31) // 32
         assert bits.is_cuda and bits.dtype in (torch.int32, torch.uint32) and bits.is_contiguous() and bits.shape[1] == W
@@ -341,8 +345,19 @@ class Decoder:
         if vn_class is not None:
             assert vn_class.is_cuda and vn_class.dtype == torch.uint8 and vn_class.numel() == self.N
         self.n_frames = bits.shape[0]
+        if n_channel is not None:
+            assert n_channel.is_cuda and n_channel.dtype == torch.int32 and n_channel.numel() == bits.shape[0]
+            _chk(_L.qldpc_load_bits_short_dev(self._h, _vp(bits.data_ptr()), _vp(llr_mag.data_ptr()),
+                                              _vp(vn_class.data_ptr()) if vn_class is not None else None, _vp(n_channel.data_ptr()), bits.shape[0]), "load_bits")
+            return
         _chk(_L.qldpc_load_bits_dev(self._h, _vp(bits.data_ptr()), _vp(llr_mag.data_ptr()),
                                     _vp(vn_class.data_ptr()) if vn_class is not None else None, bits.shape[0]), "load_bits")
+
+    def load_erasures(self, erase_bits):
+        """per-frame puncturing: packed masks [n_frames, ceil(N/32)], a set bit makes that VN of that frame an erasure (LLR 0)"""
+        torch = _torch()
+        assert erase_bits.is_cuda and erase_bits.dtype == torch.int32 and erase_bits.is_contiguous() and erase_bits.shape[1] == (self.N + 31) // 32
+        _chk(_L.qldpc_load_erasures_dev(self._h, _vp(erase_bits.data_ptr()), erase_bits.shape[0]), "load_erasures")
 
     def load_syndrome(self, synd_bits):
         """syndrome form: packed target syndromes [n_frames, ceil(M/32)] for the frames just loaded"""
@@ -492,12 +507,13 @@ def unpack_bits(words, n):
 class ReconCfg(C.Structure):
     _fields_ = [("device", C.c_int), ("efficiency", C.c_float), ("n_rates", C.c_int), ("rates", C.c_float * 8),
                 ("n_ite", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("key_quantum", C.c_int),
-                ("max_blocks", C.c_int), ("seed", C.c_uint64), ("schedule", C.c_int), ("reserved", C.c_int * 7)]
+                ("max_blocks", C.c_int), ("seed", C.c_uint64), ("schedule", C.c_int), ("mother_step", C.c_int), ("mother_max", C.c_int),
+                ("rate_gap", C.c_float), ("puncture", C.c_int), ("preload", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class ReconMsg(C.Structure):
     _fields_ = [("rate_index", C.c_uint32), ("key_bits", C.c_uint32), ("code_k", C.c_uint32), ("code_m", C.c_uint32),
-                ("crc32", C.c_uint32)]
+                ("crc32", C.c_uint32), ("n_punct", C.c_uint32)]
 
 
 _up = C.POINTER(C.c_uint32)
@@ -511,6 +527,9 @@ _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.PO
 _sig("qldpc_recon_encode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip])
 _sig("qldpc_recon_decode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip, _ip, _ip])
 _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
+_sig("qldpc_recon_parity_words", C.c_int, [C.POINTER(ReconMsg)])
+_sig("qldpc_recon_leaked_bits", C.c_int, [C.POINTER(ReconMsg)])
+_sig("qldpc_recon_entries_created", C.c_long, [_vp])
 
 
 _sig("qldpc_privamp", C.c_int, [C.c_int, _up, C.c_int, C.c_uint32, C.c_int, _up])
@@ -534,16 +553,27 @@ def crc32_words(words, n_bits):
 class Recon:
     """One side's reconciliation engine: what an ecd2 LDPC handler calls (qber_estim.c:337-340,420-423)."""
 
-    def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=50, rule="NMS", rule_param=0.75,
-                 key_quantum=1024, max_blocks=1, seed=7, schedule="flooding"):
+    def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=None, rule=None, rule_param=None,
+                 key_quantum=1024, max_blocks=1, seed=7, schedule="flooding", mother_step=None, mother_max=None, rate_gap=None,
+                 puncture=True, preload=False):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
         cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
         for i, r in enumerate(rates):
             cfg.rates[i] = float(r)
-        cfg.n_ite, cfg.rule, cfg.rule_param = int(n_ite), RULES[rule], float(rule_param)
+        if n_ite is not None:
+            cfg.n_ite = int(n_ite)
+        if rule is not None:
+            cfg.rule, cfg.rule_param = RULES[rule], float(rule_param or 0.0)
         cfg.key_quantum, cfg.max_blocks, cfg.seed = int(key_quantum), int(max_blocks), int(seed)
         cfg.schedule = SCHEDULES[schedule]
+        if mother_step is not None:
+            cfg.mother_step = int(mother_step)
+        if mother_max is not None:
+            cfg.mother_max = int(mother_max)
+        if rate_gap is not None:
+            cfg.rate_gap = float(rate_gap)
+        cfg.puncture, cfg.preload = (1 if puncture else 2), int(bool(preload))
         h = _vp()
         _chk(_L.qldpc_recon_create(C.byref(cfg), C.byref(h)), "Recon")
         self._h = h
@@ -554,11 +584,24 @@ class Recon:
         _chk(_L.qldpc_recon_plan(self._h, int(key_bits), float(qber), C.byref(m)), "Recon.plan")
         return m
 
+    @staticmethod
+    def parity_words(msg):
+        """words of disclosed parity a message carries"""
+        return int(_L.qldpc_recon_parity_words(C.byref(msg)))
+
+    @staticmethod
+    def leaked_bits(msg):
+        return int(_L.qldpc_recon_leaked_bits(C.byref(msg)))
+
+    @property
+    def entries_created(self):
+        return int(_L.qldpc_recon_entries_created(self._h))
+
     def encode(self, key_words, key_bits, qber):
         """Alice: -> (msg, parity_words)."""
         kw = np.ascontiguousarray(key_words, dtype=np.uint32)
         m = self.plan(key_bits, qber)
-        par = np.zeros((m.code_m + 31) // 32, np.uint32)
+        par = np.zeros(self.parity_words(m), np.uint32)
         _chk(_L.qldpc_recon_encode(self._h, kw.ctypes.data_as(_up), int(key_bits), float(qber), C.byref(m),
                                    par.ctypes.data_as(_up), par.size), "Recon.encode")
         return m, par
@@ -575,9 +618,15 @@ class Recon:
         return rc == 0, kw, c.value, l.value, it.value
 
     def decode_batch(self, key_words, key_bits, qber, msgs, parity_words):
+        """n blocks of one length on one code; parity_words: one uint32 array per block (they differ in length when the blocks
+        are punctured differently) or a 2-D array with ceil(code_m / 32) columns"""
         kw = np.array(key_words, dtype=np.uint32, copy=True)
         n = kw.shape[0]
-        par = np.ascontiguousarray(parity_words, dtype=np.uint32)
+        Wm = (int(msgs[0].code_m) + 31) // 32
+        par = np.zeros((n, Wm), np.uint32)
+        for i in range(n):
+            row = np.asarray(parity_words[i], dtype=np.uint32).ravel()
+            par[i, :min(Wm, row.size)] = row[:Wm]
         qb = np.ascontiguousarray(qber, dtype=np.float32)
         arr = (ReconMsg * n)(*msgs)
         st, co, it = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
@@ -593,7 +642,7 @@ class Recon:
         kb = np.ascontiguousarray(key_bits, dtype=np.int32)
         qb = np.ascontiguousarray(qber, dtype=np.float32)
         plans = [self.plan(int(b), float(p)) for b, p in zip(kb, qb)]
-        pars = [np.zeros((int(m.code_m) + 31) // 32, np.uint32) for m in plans]
+        pars = [np.zeros(self.parity_words(m), np.uint32) for m in plans]
         caps = np.array([p.size for p in pars], np.int32)
         kp = (_up * n)(*[k.ctypes.data_as(_up) for k in kws])
         pp = (_up * n)(*[p.ctypes.data_as(_up) for p in pars])

@@ -97,7 +97,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t);
-    (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
+    (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
     (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
@@ -110,7 +110,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_work); (void)hipFree(d->d_gcount); (void)hipFree(d->d_goff); (void)hipFree(d->d_llr_alt[0]); (void)hipFree(d->d_llr_alt[1]); (void)hipFree(d->d_llr8_alt[0]); (void)hipFree(d->d_llr8_alt[1]);
     for (size_t k = 1; k < d->gens.size(); k++) {
         gen_state &n = d->gens[k];
-        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd);
+        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd); (void)hipFree(n.ebits);
         (void)hipFree(n.depth); (void)hipFree(n.iters); (void)hipFree(n.origin); (void)hipFree(n.src); (void)hipFree(n.fmag); (void)hipFree(n.fnch);
     }
     delete d;
@@ -316,7 +316,7 @@ static void use_gen(qldpc_decoder *d, int k)
 {
     const gen_state &n = d->gens[(size_t)k];
     d->G = n.G;
-    d->d_sgn = n.sgn; d->d_hard = n.hard; d->d_unsat = n.unsat; d->d_done = n.done; d->d_ybits = n.ybits; d->d_synd = n.synd;
+    d->d_sgn = n.sgn; d->d_hard = n.hard; d->d_unsat = n.unsat; d->d_done = n.done; d->d_ybits = n.ybits; d->d_synd = n.synd; d->d_ebits = n.ebits;
     d->d_depth = n.depth; d->d_iters = n.iters; d->d_fmag = n.fmag; d->d_fnch = n.fnch; d->d_llr = n.llr; d->d_llr8 = n.llr8;
 }
 /* back to the batch as loaded (generation 0 = the decoder's base arrays) */
@@ -330,7 +330,7 @@ static void gen0_capture(qldpc_decoder *d)
     if (d->gens.empty()) d->gens.resize(1);
     gen_state &n = d->gens[0];
     n.G = n.cap = d->G0;
-    n.sgn = d->d_sgn; n.hard = d->d_hard; n.unsat = d->d_unsat; n.done = d->d_done; n.ybits = d->d_ybits; n.synd = d->d_synd;
+    n.sgn = d->d_sgn; n.hard = d->d_hard; n.unsat = d->d_unsat; n.done = d->d_done; n.ybits = d->d_ybits; n.synd = d->d_synd; n.ebits = d->d_ebits;
     n.depth = d->d_depth; n.iters = d->d_iters; n.origin = nullptr; n.src = nullptr; n.fmag = d->d_fmag; n.fnch = d->d_fnch; n.llr = d->d_llr; n.llr8 = d->d_llr8;
 }
 
@@ -532,7 +532,7 @@ static int compact(qldpc_decoder *d, int active_frames)
     gen_state &n = d->gens[(size_t)k];
     if (n.cap < Gn) {      /* first use (or a larger need than any run before): sized for the largest batch this generation can get */
         (void)hipStreamSynchronize(d->stream);
-        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd);
+        (void)hipFree(n.sgn); if (n.hard != n.sgn) (void)hipFree(n.hard); (void)hipFree(n.unsat); (void)hipFree(n.done); (void)hipFree(n.ybits); (void)hipFree(n.synd); (void)hipFree(n.ebits);
         (void)hipFree(n.depth); (void)hipFree(n.iters); (void)hipFree(n.origin); (void)hipFree(n.src); (void)hipFree(n.fmag); (void)hipFree(n.fnch);
         n = gen_state{};
         n.cap = std::max(Gn, std::min(o.cap, (int)(d->compact_ratio * (float)o.cap) + 1));
@@ -546,6 +546,7 @@ static int compact(qldpc_decoder *d, int active_frames)
     if (o.fmag && ((rc = gen_alloc(d, &n.fmag, C * FG)) || (rc = gen_alloc(d, &n.fnch, C * FG)))) return rc;
     if (d->llr_coded && (rc = gen_alloc(d, &n.ybits, C * d->N * V))) return rc;
     if (d->has_synd && (rc = gen_alloc(d, &n.synd, C * d->M * V))) return rc;
+    if (d->llr_coded && d->has_erase && (rc = gen_alloc(d, &n.ebits, C * d->N * V))) return rc;
     n.G = Gn;
     n.llr = nullptr; n.llr8 = nullptr;
     const bool rows8 = !d->llr_coded && d->msg_i8, rows32 = !d->llr_coded && !d->msg_i8;
@@ -571,6 +572,7 @@ static int compact(qldpc_decoder *d, int active_frames)
     LAUNCHCHK();
     if (d->llr_coded) hipLaunchKernelGGL((qk_compact_ballots<V>), dim3((unsigned)((d->N + 64 * QK_WAVES - 1) / (64 * QK_WAVES)), (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.ybits, n.ybits, n.src, d->N);
     if (d->has_synd) hipLaunchKernelGGL((qk_compact_ballots<V>), dim3((unsigned)((d->M + 64 * QK_WAVES - 1) / (64 * QK_WAVES)), (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.synd, n.synd, n.src, d->M);
+    if (d->llr_coded && d->has_erase) hipLaunchKernelGGL((qk_compact_ballots<V>), dim3((unsigned)((d->N + 64 * QK_WAVES - 1) / (64 * QK_WAVES)), (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.ebits, n.ebits, n.src, d->N);
     const unsigned bx = (unsigned)std::max(1, std::min((d->N + QK_WAVES - 1) / QK_WAVES, 8192 / std::max(1, Gn)));
     if (rows32) hipLaunchKernelGGL((qk_compact_rows<V, float>), dim3(bx, (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, o.llr, n.llr, n.src, d->N, 1.0f);
     if (rows8) hipLaunchKernelGGL((qk_compact_rows<V, uint8_t>), dim3(bx, (unsigned)Gn), dim3(QK_THREADS), 0, d->stream, (const uint8_t *)o.llr8, (uint8_t *)n.llr8, n.src, d->N, (uint8_t)0);
@@ -875,6 +877,7 @@ extern "C" int qldpc_load_llr_dev(qldpc_decoder *d, const float *d_llr, int n_fr
     view_reset(d);
     d->n_frames = n_frames;
     d->has_synd = 0;
+    d->has_erase = 0;
     d->llr_coded = 0;
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, 2.0 * d->N * 4.0 * n_frames);
@@ -918,6 +921,7 @@ extern "C" int qldpc_load_bits_short_dev(qldpc_decoder *d, const uint32_t *d_bit
     view_reset(d);
     d->n_frames = n_frames;
     d->has_synd = 0;
+    d->has_erase = 0;
     const int W = (d->N + 31) / 32;
     if (d->engine == QLDPC_ENGINE_EDGES) {
         prof_scope ps(d, KS_LOAD, ((double)W * 4.0 + d->N * 4.0) * n_frames);
@@ -999,6 +1003,49 @@ extern "C" int qldpc_load_syndrome_dev(qldpc_decoder *d, const uint32_t *d_synd_
         LAUNCHCHK();
     }
     d->has_synd = 1; d->ran = 0;
+    return QLDPC_OK;
+}
+
+/*
+ * Per-frame puncturing: d_erase_bits[n_frames][ceil(N/32)] packed MSB-first, a set bit makes that VN of that frame an erasure
+ * (channel LLR 0, BS/src/main.cpp:359-362) whatever its class.  For the frames just loaded (cleared again by the next qldpc_load_*).
+ */
+extern "C" int qldpc_load_erasures_dev(qldpc_decoder *d, const uint32_t *d_erase_bits, int n_frames)
+{
+    if (!d || !d_erase_bits) return QLDPC_EINVAL;
+    if (!d->loaded || n_frames != d->n_frames) { qldpc_set_error("qldpc_load_erasures_dev: load %d frames first (have %d)", n_frames, d->loaded ? d->n_frames : 0); return QLDPC_ESTATE; }
+    HIPCHK(hipSetDevice(d->device));
+    view_reset(d);
+    const int W = (d->N + 31) / 32;
+    int rc;
+    if (d->engine == QLDPC_ENGINE_EDGES) {
+        hipLaunchKernelGGL(qe_erase, dim3((unsigned)std::min((d->N + 255) / 256, 256), (unsigned)n_frames), dim3(256), 0, d->stream, d_erase_bits, d->d_llr, d->N, W);
+        LAUNCHCHK();
+        d->ran = 0;
+        return QLDPC_OK;
+    }
+    dim3 grid((unsigned)std::max(1, std::min((W + QK_WAVES - 1) / QK_WAVES, 4096 / std::max(1, d->G))), (unsigned)d->G);
+    if (d->llr_coded) {
+        if (!d->d_ebits && (rc = dev_alloc(d, &d->d_ebits, (size_t)d->G * d->N * d->V))) return rc;
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_load_syndrome<1>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_ebits, d->N, W, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_load_syndrome<2>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_ebits, d->N, W, n_frames); break;
+        default: hipLaunchKernelGGL((qk_load_syndrome<4>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_ebits, d->N, W, n_frames); break;
+        }
+        LAUNCHCHK();
+        d->has_erase = 1; d->ran = 0;
+        return QLDPC_OK;
+    }
+    if (d->msg_i8) hipLaunchKernelGGL((qk_erase_rows<4, uint8_t>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, (uint8_t *)d->d_llr8, d->N, W, n_frames);
+    else {
+        switch (d->V) {
+        case 1: hipLaunchKernelGGL((qk_erase_rows<1, float>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_llr, d->N, W, n_frames); break;
+        case 2: hipLaunchKernelGGL((qk_erase_rows<2, float>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_llr, d->N, W, n_frames); break;
+        default: hipLaunchKernelGGL((qk_erase_rows<4, float>), grid, dim3(QK_THREADS), 0, d->stream, d_erase_bits, d->d_llr, d->N, W, n_frames); break;
+        }
+    }
+    LAUNCHCHK();
+    d->ran = 0;
     return QLDPC_OK;
 }
 

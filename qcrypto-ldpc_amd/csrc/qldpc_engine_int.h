@@ -40,7 +40,7 @@ struct bucket { int cap; int n; int *d_list; };   /* cap = register-resident deg
  */
 struct gen_state {
     int G, cap;                          /* groups in use / allocated */
-    u64 *sgn, *hard, *unsat, *done, *ybits, *synd;
+    u64 *sgn, *hard, *unsat, *done, *ybits, *synd, *ebits;
     int *depth, *iters, *origin, *src;   /* origin[slot] = frame index in the caller's batch (-1: padding); src[slot] = slot in the previous generation */
     float *fmag; int *fnch;
     float *llr; uint32_t *llr8;          /* channel LLR rows in this generation's layout (NULL with coded LLRs) */
@@ -88,6 +88,7 @@ struct qldpc_decoder {
     int msg_half;                    /* 1: v2c / c2v stored as binary16 (flooding, frames engine) */
     /* coded channel LLRs (flooding, fp32 / binary16 messages, after qldpc_load_bits_*): no LLR array is read, see qk_coded_llr */
     u64 *d_ybits; float *d_fmag; int *d_fnch; uint8_t *d_vcls; int llr_coded;
+    u64 *d_ebits; int has_erase;     /* [G][N][V] per-frame erasure ballots of the coded form (allocated on first use), set by qldpc_load_erasures_dev */
     int post_closes_run;             /* set around the _compute_post that ends an early-exit run (not for posterior read-back) */
     int packed_h16;                  /* binary16 variant: use the packed check-node kernel when V == 2 (QLDPC_PACKED_H16=0 turns it off) */
     int msg_i8;                      /* 1: 8-bit fixed-point messages and integer arithmetic (flooding min-sum family, frames engine, V = 4) */

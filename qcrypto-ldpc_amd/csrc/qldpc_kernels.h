@@ -317,6 +317,7 @@ struct qk_coded_llr {
     const float *fmag;         /* [G*FG] |LLR| of a channel bit of each frame (padding: 1)  */
     const int *fnch;           /* [G*FG] class-0 VNs at index >= fnch[f] are pinned (shortening) */
     const uint8_t *vcls;       /* [N] VN class                                               */
+    const u64 *ebits;          /* [G][N][V] per-frame erasures as ballots (qldpc_load_erasures_dev), or NULL */
 };
 
 
@@ -327,7 +328,8 @@ template <int V> __device__ __forceinline__ void qk_coded_y(float (&y)[V], const
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const bool bit = (c.ybits[((size_t)g * N + v) * V + j] >> lane) & 1ull;
-        const float m = (cls == 0) ? (v < nc[j] ? mg[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
+        float m = (cls == 0) ? (v < nc[j] ? mg[j] : 23.025850929840455f) : (cls == 1 ? 23.025850929840455f : 0.0f);
+        if (c.ebits && ((c.ebits[((size_t)g * N + v) * V + j] >> lane) & 1ull)) m = 0.0f;      /* punctured for this frame: LLR 0 (BS/src/main.cpp:359-362) */
         y[j] = bit ? -m : m;
     }
 }
@@ -987,6 +989,33 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_bits(const uint32_t *__res
                 o[j] = live[j] ? (y ? -m : m) : 1.0f;
             }
             qk_store<V>(dst + ((size_t)g * N + v) * FG + lane * V, o);
+        }
+    }
+}
+
+/*
+ * Per-frame puncturing (BS/src/main.cpp:359-362: LLR[pattern[i]] = 0) for decoders that read an LLR array: erase[n_frames][W]
+ * packed MSB-first, a set bit zeroes that VN's channel LLR of that frame.  T = float ([G][N][FG]) or uint8_t (the 8-bit form).
+ */
+template <int V, typename T>
+__global__ __launch_bounds__(QK_THREADS) void qk_erase_rows(const uint32_t *__restrict__ erase, T *__restrict__ llr, int N, int W, int n_frames)
+{
+    constexpr int FG = 64 * V;
+    const int g = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int w = blockIdx.x * QK_WAVES + wave; w < W; w += gridDim.x * QK_WAVES) {
+        uint32_t word[V];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < V; j++) { const int f = g * FG + lane * V + j; word[j] = f < n_frames ? erase[(size_t)f * W + w] : 0u; any = any || word[j] != 0u; }
+        if (!__any(any)) continue;
+        for (int b = 0; b < 32; b++) {
+            const int v = w * 32 + b;
+            if (v >= N) break;
+#pragma unroll
+            for (int j = 0; j < V; j++)
+                if ((word[j] >> (31 - b)) & 1u) llr[((size_t)g * N + v) * FG + lane * V + j] = (T)0;
         }
     }
 }

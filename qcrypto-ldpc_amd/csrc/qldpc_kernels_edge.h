@@ -221,6 +221,14 @@ __global__ void qe_load_bits(const uint32_t *__restrict__ bits, const float *__r
     }
 }
 
+/* per-frame puncturing for the frame-major floats: erase[F][W] packed MSB-first, a set bit zeroes that LLR */
+__global__ void qe_erase(const uint32_t *__restrict__ erase, float *__restrict__ llr, int N, int W)
+{
+    const int f = blockIdx.y;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x)
+        if ((erase[(size_t)f * W + (v >> 5)] >> (31 - (v & 31))) & 1u) llr[(size_t)f * N + v] = 0.0f;
+}
+
 __global__ void qe_fetch_info(const uint32_t *__restrict__ hard, const int *__restrict__ info_pos, int *__restrict__ out, int K, int W)
 {
     const int f = blockIdx.y;

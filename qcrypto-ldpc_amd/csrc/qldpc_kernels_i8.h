@@ -246,7 +246,8 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
 #pragma unroll
             for (int j = 0; j < QI_V; j++) {
                 const bool bit = (coded.ybits[((size_t)g * N + vv[u]) * QI_V + j] >> lane) & 1ull;
-                const int m = (cls == 0) ? (vv[u] < nc[j] ? qm[j] : qpin) : (cls == 1 ? qpin : 0);
+                int m = (cls == 0) ? (vv[u] < nc[j] ? qm[j] : qpin) : (cls == 1 ? qpin : 0);
+                if (coded.ebits && ((coded.ebits[((size_t)g * N + vv[u]) * QI_V + j] >> lane) & 1ull)) m = 0;
                 w |= (uint32_t)((bit ? -m : m) & 0xff) << (8 * j);
             }
             y[u] = w;

@@ -16,7 +16,7 @@ static void launch_cn_one(qldpc_decoder *d, const bucket &b, bool first)
     dim3 grid((unsigned)grid_x(b.n, 1), (unsigned)d->G);
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     if (first && !d->msg_i8) {      /* iteration 0 with coded LLRs: inputs rebuilt from the received bits, var_to_chk is not read (see qk_cn_flood FIRST) */
-        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls, d->has_erase ? d->d_ebits : nullptr};
         if (d->msg_half)
             hipLaunchKernelGGL((qk_cn_flood<V, CAP, FAM, __half, true>), grid, dim3(QK_THREADS), 0, d->stream, (const __half *)d->d_a, (__half *)d->d_b, b.d_list, b.n,
                                d->d_cn_ptr, d->d_cn_tr, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->d_cn_var, d->N, c);
@@ -127,7 +127,7 @@ static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
 {
     dim3 grid((unsigned)grid_x(b.n, UNX), (unsigned)d->G);
     if (d->llr_coded) {
-        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+        qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls, d->has_erase ? d->d_ebits : nullptr};
         hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, true>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, (const float *)nullptr, (MT *)d->d_a, d->d_sgn, d->d_hard,
                            post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c, want_ballots(d, MODE));
         return;
@@ -143,7 +143,7 @@ static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
         if constexpr (V == QI_V) {
             dim3 grid((unsigned)grid_x(b.n, UN), (unsigned)d->G);
             if (d->llr_coded) {
-                qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls};
+                qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls, d->has_erase ? d->d_ebits : nullptr};
                 hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, (const uint32_t *)nullptr, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
                                    post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale, want_ballots(d, MODE));
             } else

@@ -35,18 +35,24 @@ struct recon_entry {
     qldpc_code *code;
     qldpc_encoder *enc;
     qldpc_decoder *dec;
-    uint8_t *d_cls;       /* [N] */
-    uint32_t *d_bits;     /* [max_blocks][Wn] */
+    uint8_t *d_cls;       /* [N]: key VNs channel, parity VNs pinned */
+    uint32_t *d_key;      /* [max_blocks][Wk]  key words as handed in (Bob) / information words (Alice) */
+    uint32_t *d_disc;     /* [max_blocks][Wm]  disclosed parity bits, packed */
+    uint32_t *d_bits;     /* [max_blocks][Wn]  assembled frames */
+    uint32_t *d_erase;    /* [max_blocks][Wn]  per-frame puncturing masks */
     uint32_t *d_out;      /* [max_blocks][Wn] */
     float *d_mag;         /* [max_blocks] */
     int *d_iters, *d_ok;  /* [max_blocks] */
     int *d_nch;           /* [max_blocks] channel VNs per frame (block length) */
-    int cls_key_bits;     /* K once the class mask is built */
+    int *d_np;            /* [max_blocks] punctured parity VNs per frame */
 };
 
 struct qldpc_recon {
     qldpc_recon_cfg cfg;
+    float gap;
     std::list<recon_entry> cache;   /* most recently used first */
+    size_t keep;                    /* entries the cache may hold (all mother codes when they are preloaded) */
+    long created;                   /* entries built so far (tests: nothing is built after a preload) */
 };
 
 static const uint32_t *crc_table()
@@ -86,12 +92,83 @@ extern "C" void qldpc_recon_cfg_default(qldpc_recon_cfg *c)
     c->efficiency = 1.4f;
     c->n_rates = 4;
     c->rates[0] = 0.5f; c->rates[1] = 0.7f; c->rates[2] = 0.8f; c->rates[3] = 0.9f;
-    c->n_ite = 50;
-    c->rule = QLDPC_RULE_NMS;
-    c->rule_param = 0.75f;
+    c->n_ite = 60;
+    c->rule = QLDPC_RULE_SPA;       /* the harness default (BS/src/main.cpp:193); punctured VNs need it: measured FER 0 where NMS fails */
+    c->rule_param = 0.0f;
     c->key_quantum = 1024;
     c->max_blocks = 1;
     c->seed = 7;
+    c->mother_step = 8192;
+    c->mother_max = 65536;
+    c->rate_gap = 0.0f;             /* 0 = by rule: 0.03 for SPA, 0.05 for the min-sum family */
+    c->puncture = 1;
+    c->preload = 0;
+}
+
+/*
+ * Punctured parity positions of a block: p of the M accumulator bits, evenly spaced (position j is punctured iff
+ * floor((j + 1) p / M) > floor(j p / M)), so no check loses both of its parity neighbours while p <= M / 2 and the pattern needs
+ * no table or seed: both sides compute it from (M, p).  The reference shuffles the parity positions at random and searches for
+ * good patterns (BS/src/main.cpp:305-333); on this accumulator structure random patterns fail where the even one decodes
+ * (tools/punct_probe.py: 37 % punctured at QBER 4 %: FER 0.07 random, 0 even; 49 % at 3 %: 1.0 vs 0).
+ */
+__host__ __device__ static inline int punct_before(int j, int p, int M) { return (int)(((long long)j * p) / M); }      /* punctured positions in [0, j) */
+__host__ __device__ static inline bool punct_at(int j, int p, int M) { return punct_before(j + 1, p, M) > punct_before(j, p, M); }
+
+/* Bob: frame words + puncturing mask of every block from its key words and the disclosed parity bits */
+__global__ __launch_bounds__(256) void rk_assemble(const uint32_t *__restrict__ key, const uint32_t *__restrict__ disc, const int *__restrict__ key_bits,
+                                                   const int *__restrict__ n_punct, uint32_t *__restrict__ bits, uint32_t *__restrict__ erase,
+                                                   int Wk, int Wn, int Wm, int M)
+{
+    const int b = blockIdx.y;
+    const int kb = key_bits[b], p = n_punct[b];
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < Wn; w += gridDim.x * blockDim.x) {
+        uint32_t word = 0, er = 0;
+        if (w < Wk) {
+            const int lo = w * 32;
+            if (lo < kb) {
+                word = key[(size_t)b * Wk + w];
+                if (kb - lo < 32) word &= 0xFFFFFFFFu << (32 - (kb - lo));      /* shortened positions are known zeros */
+            }
+        } else {
+            const uint32_t *dw = disc + (size_t)b * Wm;
+            for (int t = 0; t < 32; t++) {
+                const int j = (w - Wk) * 32 + t;
+                if (j >= M) break;
+                if (punct_at(j, p, M)) er |= 1u << (31 - t);
+                else {
+                    const int r = j - punct_before(j, p, M);
+                    word |= ((dw[r >> 5] >> (31 - (r & 31))) & 1u) << (31 - t);
+                }
+            }
+        }
+        bits[(size_t)b * Wn + w] = word;
+        erase[(size_t)b * Wn + w] = er;
+    }
+}
+
+/* Alice: the disclosed (non-punctured) parity bits of every codeword, packed in position order */
+__global__ __launch_bounds__(256) void rk_disclose(const uint32_t *__restrict__ cw, const int *__restrict__ n_punct, uint32_t *__restrict__ disc,
+                                                   int Wk, int Wn, int Wm, int M)
+{
+    const int b = blockIdx.y;
+    const int p = n_punct[b], d = M - p;
+    const uint32_t *par = cw + (size_t)b * Wn + Wk;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < Wm; w += gridDim.x * blockDim.x) {
+        uint32_t word = 0;
+        for (int t = 0; t < 32; t++) {
+            const int r = w * 32 + t;
+            if (r >= d) break;
+            /* the r-th disclosed position: smallest j with (j + 1) - punct_before(j + 1) == r + 1 */
+            int lo = r, hi = r + p;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (mid + 1 - punct_before(mid + 1, p, M) >= r + 1) hi = mid; else lo = mid + 1;
+            }
+            word |= ((par[lo >> 5] >> (31 - (lo & 31))) & 1u) << (31 - t);
+        }
+        disc[(size_t)b * Wm + w] = word;
+    }
 }
 
 static void entry_free(recon_entry &e)
@@ -99,7 +176,8 @@ static void entry_free(recon_entry &e)
     qldpc_decoder_free(e.dec);
     qldpc_encoder_free(e.enc);
     qldpc_code_free(e.code);
-    (void)hipFree(e.d_cls); (void)hipFree(e.d_bits); (void)hipFree(e.d_out); (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok); (void)hipFree(e.d_nch);
+    (void)hipFree(e.d_cls); (void)hipFree(e.d_key); (void)hipFree(e.d_disc); (void)hipFree(e.d_bits); (void)hipFree(e.d_erase); (void)hipFree(e.d_out);
+    (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok); (void)hipFree(e.d_nch); (void)hipFree(e.d_np);
 }
 
 extern "C" void qldpc_recon_free(qldpc_recon *r)
@@ -110,13 +188,28 @@ extern "C" void qldpc_recon_free(qldpc_recon *r)
     delete r;
 }
 
+/* code dimensions of a block of key_bits on table rate R: a mother code (K a multiple of mother_step, the block is shortened) up to
+ * mother_max bits, otherwise a code of its own size (K = key_bits rounded up to key_quantum) */
+static void code_dims(const qldpc_recon_cfg &c, int key_bits, double R, int *K, int *M)
+{
+    int k;
+    if (c.mother_step > 0 && key_bits <= c.mother_max) k = (key_bits + c.mother_step - 1) / c.mother_step * c.mother_step;
+    else k = (key_bits + c.key_quantum - 1) / c.key_quantum * c.key_quantum;
+    int m = (int)llround((double)k * (1.0 - R) / R);
+    if (m < 2) m = 2;
+    *K = k; *M = m;
+}
+
+static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out);
+
 extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
 {
     if (!out) return QLDPC_EINVAL;
     *out = nullptr;
     if (!cfg) return QLDPC_EINVAL;
     if (cfg->n_rates < 1 || cfg->n_rates > 8 || cfg->key_quantum < 32 || (cfg->key_quantum & 31) || cfg->max_blocks < 1 || cfg->n_ite < 1 ||
-        !(cfg->efficiency > 0.0f)) {
+        !(cfg->efficiency > 0.0f) || cfg->mother_step < 0 || (cfg->mother_step & 31) || (cfg->mother_step > 0 && cfg->mother_max < cfg->mother_step) ||
+        !(cfg->rate_gap >= 0.0f && cfg->rate_gap < 0.5f) || cfg->reserved[0] || cfg->reserved[1]) {
         qldpc_set_error("recon_create: bad configuration");
         return QLDPC_EINVAL;
     }
@@ -128,30 +221,74 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     qldpc_recon *r = new (std::nothrow) qldpc_recon();
     if (!r) return QLDPC_ENOMEM;
     r->cfg = *cfg;
+    r->gap = cfg->rate_gap > 0.0f ? cfg->rate_gap : (cfg->rule == QLDPC_RULE_SPA || cfg->rule == QLDPC_RULE_LSPA ? 0.035f : 0.05f);
+    const size_t mothers = cfg->mother_step > 0 ? (size_t)(cfg->mother_max / cfg->mother_step) * (size_t)cfg->n_rates : 0;
+    r->keep = mothers + 6;
+    r->created = 0;
+    if (cfg->preload && mothers) {
+        /* every (mother size, table rate) pair now: code, encoder, decoder and staging buffers, so that no block of up to mother_max
+         * bits builds a code or allocates device memory later (the daemon calls this from ldpc_init) */
+        if (hipSetDevice(cfg->device) != hipSuccess) { delete r; return QLDPC_EHIP; }
+        for (int k = cfg->mother_step; k <= cfg->mother_max; k += cfg->mother_step)
+            for (int i = 0; i < cfg->n_rates; i++) {
+                int K, M;
+                code_dims(r->cfg, k, cfg->rates[i], &K, &M);
+                recon_entry *e;
+                const int rc = get_entry(r, K, M, &e);
+                if (rc) { qldpc_recon_free(r); return rc; }
+            }
+    }
     *out = r;
     return QLDPC_OK;
 }
 
-/* rate = largest table entry <= min_cr(QBER, f) = 1 / (1 + f h(QBER))   (BS/src/main.cpp:29,241-266) */
+extern "C" long qldpc_recon_entries_created(const qldpc_recon *r) { return r ? r->created : -1; }
+
+/*
+ * Rate choice, code dimensions and puncturing of a block (BS/src/main.cpp:29-34,235-311).  The QBER estimate is clamped to
+ * [0.001, 0.25] first: the daemon's localError is exactly 0 when the test sample held no error (qber_estim.c:26).
+ *   target rate  R* = min( 1 / (1 + f h(q)),  1 - h(q) - rate_gap (65536 / K)^0.4 )   the harness's min_cr, kept away from capacity
+ *   table rate   R  = largest entry <= R*                                  (BS/src/main.cpp:241-266)
+ *   code         K >= key_bits information VNs (mother code, shortened), M = round(K (1 - R) / R) parity VNs
+ *   disclosed    d = ceil(key_bits (1 / R* - 1)) parity bits, the other p = M - d are punctured (parity_bits_to_punct with the block's
+ *                own length for the information bits), at most 65 % of M
+ * leak = d + 32 (CRC).
+ */
+#define RECON_PUNCT_CAP 0.65
+static float clamp_qber(float q) { return !(q > 0.001f) ? 0.001f : (q > 0.25f ? 0.25f : q); }
+
 extern "C" int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon_msg *msg)
 {
     if (!r || !msg) return QLDPC_EINVAL;
     if (key_bits < 32) { qldpc_set_error("recon_plan: key_bits=%d", key_bits); return QLDPC_ESIZE; }
-    if (!(qber > 0.0f && qber < 0.5f)) { qldpc_set_error("recon_plan: qber=%g not in (0, 0.5)", (double)qber); return QLDPC_EINVAL; }
-    const float need = qldpc_min_code_rate(qber, r->cfg.efficiency);
+    if (!(qber >= 0.0f && qber < 0.5f)) { qldpc_set_error("recon_plan: qber=%g not in [0, 0.5)", (double)qber); return QLDPC_EINVAL; }
+    const float q = clamp_qber(qber);
+    const double h = qldpc_binary_entropy(q);
+    /* the distance a code needs from capacity grows as it gets shorter: measured clean (FER 0 / 128 per point, QBER 0.3 .. 8 %, SPA) at
+     * 0.035 for K = 65 536, 0.042 for 32 768, 0.06 for 16 384 and 8 192 (tools/punct_probe.py) -- rate_gap (65536 / K)^0.4 covers them */
+    int K0, M0;
+    code_dims(r->cfg, key_bits, 0.5, &K0, &M0);
+    const double gap = (double)r->gap * pow(65536.0 / (double)K0, 0.4);
+    double need = qldpc_min_code_rate(q, r->cfg.efficiency);
+    if (1.0 - h - gap < need) need = 1.0 - h - gap;
     int idx = -1;
     for (int i = 0; i < r->cfg.n_rates; i++) if (r->cfg.rates[i] <= need) idx = i;
-    if (idx < 0) { qldpc_set_error("recon_plan: QBER %.4f needs rate <= %.3f, below the table", (double)qber, (double)need); return QLDPC_EUNSUPPORTED; }
-    const int q = r->cfg.key_quantum;
-    const int K = (key_bits + q - 1) / q * q;
-    const double R = r->cfg.rates[idx];
-    int M = (int)llround((double)K * (1.0 - R) / R);
-    if (M < 2) M = 2;
+    if (idx < 0) { qldpc_set_error("recon_plan: QBER %.4f needs rate <= %.3f, below the table", (double)qber, need); return QLDPC_EUNSUPPORTED; }
+    int K, M;
+    code_dims(r->cfg, key_bits, r->cfg.rates[idx], &K, &M);
+    int p = 0;
+    if (r->cfg.puncture == 1) {
+        const int d = (int)ceil((double)key_bits * (1.0 / need - 1.0));
+        p = M - d;
+        if (p > (int)(RECON_PUNCT_CAP * M)) p = (int)(RECON_PUNCT_CAP * M);
+        if (p < 0) p = 0;
+    }
     memset(msg, 0, sizeof(*msg));
     msg->rate_index = (uint32_t)idx;
     msg->key_bits = (uint32_t)key_bits;
     msg->code_k = (uint32_t)K;
     msg->code_m = (uint32_t)M;
+    msg->n_punct = (uint32_t)p;
     return QLDPC_OK;
 }
 
@@ -161,8 +298,8 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
         if (it->K == K && it->M == M) { r->cache.splice(r->cache.begin(), r->cache, it); *out = &r->cache.front(); return QLDPC_OK; }
     recon_entry e;
     memset(&e, 0, sizeof(e));
-    e.K = K; e.M = M; e.cls_key_bits = -1;
-    const int N = K + M, Wn = (N + 31) / 32, B = r->cfg.max_blocks;
+    e.K = K; e.M = M;
+    const int N = K + M, Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32, B = r->cfg.max_blocks;
     int rc = qldpc_code_ira(N, K, 0.125f, 11, 3, r->cfg.seed, &e.code);
     if (!rc) rc = qldpc_encoder_create(e.code, "IRA", r->cfg.device, &e.enc);
     if (!rc) {
@@ -172,60 +309,85 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
         dc.enable_syndrome = 1; dc.syndrome_depth = 1; dc.max_frames = B; dc.device = r->cfg.device;
         rc = qldpc_decoder_create(e.code, K, nullptr, &dc, &e.dec);
     }
-    if (!rc && hipMalloc((void **)&e.d_cls, (size_t)N) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_bits, sizeof(uint32_t) * (size_t)B * Wn) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_out, sizeof(uint32_t) * (size_t)B * Wn) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_mag, sizeof(float) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_iters, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_ok, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipMalloc((void **)&e.d_nch, sizeof(int) * (size_t)B) != hipSuccess) rc = QLDPC_ENOMEM;
+    auto alloc = [&](void **ptr, size_t bytes) { if (!rc && hipMalloc(ptr, bytes) != hipSuccess) rc = QLDPC_ENOMEM; };
+    alloc((void **)&e.d_cls, (size_t)N);
+    alloc((void **)&e.d_key, sizeof(uint32_t) * (size_t)B * Wk);
+    alloc((void **)&e.d_disc, sizeof(uint32_t) * (size_t)B * Wm);
+    alloc((void **)&e.d_bits, sizeof(uint32_t) * (size_t)B * Wn);
+    alloc((void **)&e.d_erase, sizeof(uint32_t) * (size_t)B * Wn);
+    alloc((void **)&e.d_out, sizeof(uint32_t) * (size_t)B * Wn);
+    alloc((void **)&e.d_mag, sizeof(float) * (size_t)B);
+    alloc((void **)&e.d_iters, sizeof(int) * (size_t)B);
+    alloc((void **)&e.d_ok, sizeof(int) * (size_t)B);
+    alloc((void **)&e.d_nch, sizeof(int) * (size_t)B);
+    alloc((void **)&e.d_np, sizeof(int) * (size_t)B);
+    if (!rc) {
+        std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* parity VNs are disclosed; key VNs past a block's length are pinned per frame */
+        for (int i = 0; i < K; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
+        if (hipMemcpy(e.d_cls, cls.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) rc = QLDPC_EHIP;
+    }
     if (rc) { entry_free(e); return rc; }
-    while (r->cache.size() >= 6) { entry_free(r->cache.back()); r->cache.pop_back(); }
+    while (r->cache.size() >= r->keep) { entry_free(r->cache.back()); r->cache.pop_back(); }
     r->cache.push_front(e);
+    r->created++;
     *out = &r->cache.front();
     return QLDPC_OK;
 }
 
+/* a message header must describe the block it came with AND be what the local plan gives for its rate index: the peer cannot make
+ * this side build a code of its own choosing */
 static int check_msg(const qldpc_recon *r, const qldpc_recon_msg *m, int key_bits)
 {
-    const int q = r->cfg.key_quantum;
-    if ((int)m->key_bits != key_bits || (int)m->code_k != (key_bits + q - 1) / q * q || m->code_m < 2 || m->rate_index >= (uint32_t)r->cfg.n_rates ||
-        m->code_k > (1u << 26) || m->code_m > (1u << 26)) {
-        qldpc_set_error("recon: message header does not match the block (key_bits %u vs %d, K %u, M %u)", m->key_bits, key_bits, m->code_k, m->code_m);
+    int K = 0, M = 0;
+    const bool idx_ok = m->rate_index < (uint32_t)r->cfg.n_rates;
+    if (idx_ok && key_bits >= 32) code_dims(r->cfg, key_bits, r->cfg.rates[m->rate_index], &K, &M);
+    if (!idx_ok || key_bits < 32 || (int)m->key_bits != key_bits || (int)m->code_k != K || (int)m->code_m != M || m->n_punct > (uint32_t)(RECON_PUNCT_CAP * M) ||
+        (r->cfg.puncture != 1 && m->n_punct != 0)) {
+        qldpc_set_error("recon: message header does not match the block (key_bits %u vs %d, rate index %u, K %u vs %d, M %u vs %d, punctured %u)",
+                        m->key_bits, key_bits, m->rate_index, m->code_k, K, m->code_m, M, m->n_punct);
         return QLDPC_ESIZE;
     }
     return QLDPC_OK;
 }
 
-extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber, qldpc_recon_msg *msg, uint32_t *parity_words, int cap)
+/* blocks of ONE entry (same K, M): one encoder launch.  parity[i] receives ceil((M - n_punct) / 32) words. */
+static int encode_group(qldpc_recon *r, int n, const uint32_t *const *key, const int *key_bits, qldpc_recon_msg *const *msgs, uint32_t *const *parity)
 {
-    if (!r || !key_words || !msg || !parity_words) return QLDPC_EINVAL;
-    int rc = qldpc_recon_plan(r, key_bits, qber, msg);
-    if (rc) return rc;
-    const int K = (int)msg->code_k, M = (int)msg->code_m, N = K + M;
-    const int Wk = K / 32, Wkey = (key_bits + 31) / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
-    if (cap < Wm) { qldpc_set_error("recon_encode: parity buffer holds %d words, need %d", cap, Wm); return QLDPC_ESIZE; }
-    HIPCHK(hipSetDevice(r->cfg.device));
+    const int K = (int)msgs[0]->code_k, M = (int)msgs[0]->code_m, N = K + M;
+    const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
+    int rc;
     recon_entry *e;
     if ((rc = get_entry(r, K, M, &e))) return rc;
-    std::vector<uint32_t> info((size_t)Wk, 0u), cw((size_t)Wn);
-    memcpy(info.data(), key_words, sizeof(uint32_t) * (size_t)Wkey);
-    if (key_bits & 31) info[(size_t)Wkey - 1] &= 0xFFFFFFFFu << (32 - (key_bits & 31));
-    HIPCHK(hipMemcpy(e->d_bits, info.data(), sizeof(uint32_t) * (size_t)Wk, hipMemcpyHostToDevice));
-    if ((rc = qldpc_encode_packed_dev(e->enc, e->d_bits, e->d_out, 1, nullptr))) return rc;
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(cw.data(), e->d_out, sizeof(uint32_t) * (size_t)Wn, hipMemcpyDeviceToHost));
-    /* parity bits are codeword bits K..N-1; K is word aligned */
-    memset(parity_words, 0, sizeof(uint32_t) * (size_t)Wm);
-    memcpy(parity_words, cw.data() + Wk, sizeof(uint32_t) * (size_t)(Wn - Wk));
-    msg->crc32 = qldpc_crc32_words(key_words, key_bits);
+    std::vector<uint32_t> info((size_t)n * Wk, 0u), disc((size_t)n * Wm);
+    std::vector<int> np((size_t)n);
+    for (int t = 0; t < n; t++) {
+        const int kb = key_bits[t], Wkey = (kb + 31) / 32;
+        uint32_t *f = info.data() + (size_t)t * Wk;
+        memcpy(f, key[t], sizeof(uint32_t) * (size_t)Wkey);
+        if (kb & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (kb & 31));
+        np[(size_t)t] = (int)msgs[t]->n_punct;
+    }
+    HIPCHK(hipMemcpy(e->d_key, info.data(), sizeof(uint32_t) * info.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_np, np.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    if ((rc = qldpc_encode_packed_dev(e->enc, e->d_key, e->d_out, n, nullptr))) return rc;
+    hipLaunchKernelGGL(rk_disclose, dim3((unsigned)((Wm + 255) / 256), (unsigned)n), dim3(256), 0, 0, e->d_out, e->d_np, e->d_disc, Wk, Wn, Wm, M);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(disc.data(), e->d_disc, sizeof(uint32_t) * disc.size(), hipMemcpyDeviceToHost));
+    for (int t = 0; t < n; t++) {
+        const int Wd = (M - np[(size_t)t] + 31) / 32;
+        memcpy(parity[t], disc.data() + (size_t)t * Wm, sizeof(uint32_t) * (size_t)Wd);
+        msgs[t]->crc32 = qldpc_crc32_words(key[t], key_bits[t]);
+    }
     return QLDPC_OK;
 }
 
+extern "C" int qldpc_recon_parity_words(const qldpc_recon_msg *msg) { return msg ? (int)((msg->code_m - msg->n_punct + 31) / 32) : QLDPC_EINVAL; }
+extern "C" int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg) { return msg ? (int)(msg->code_m - msg->n_punct) + 32 : QLDPC_EINVAL; }
+
 /*
  * Alice's side for many blocks at once: plans every block (msgs[i] is filled as by qldpc_recon_encode), groups the blocks by
- * plan and encodes each group in launches of up to max_blocks frames.  parity_words[i] must hold ceil(code_m / 32) words
- * (parity_cap[i] words are available).
+ * code and encodes each group in launches of up to max_blocks frames.  parity_words[i] receives qldpc_recon_parity_words(&msgs[i])
+ * words (parity_cap[i] are available).
  */
 extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *const *key_words, const int *key_bits, const float *qber,
                                          qldpc_recon_msg *msgs, uint32_t *const *parity_words, const int *parity_cap)
@@ -235,7 +397,7 @@ extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *
     for (int i = 0; i < n; i++) {
         if (!key_words[i] || !parity_words[i]) return QLDPC_EINVAL;
         if ((rc = qldpc_recon_plan(r, key_bits[i], qber[i], &msgs[i]))) return rc;
-        if (parity_cap[i] < ((int)msgs[i].code_m + 31) / 32) { qldpc_set_error("recon_encode_blocks: parity buffer %d holds %d words, need %d", i, parity_cap[i], ((int)msgs[i].code_m + 31) / 32); return QLDPC_ESIZE; }
+        if (parity_cap[i] < qldpc_recon_parity_words(&msgs[i])) { qldpc_set_error("recon_encode_blocks: parity buffer %d holds %d words, need %d", i, parity_cap[i], qldpc_recon_parity_words(&msgs[i])); return QLDPC_ESIZE; }
     }
     HIPCHK(hipSetDevice(r->cfg.device));
     std::vector<char> taken((size_t)n, 0);
@@ -244,64 +406,58 @@ extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *
         std::vector<int> idx;
         for (int j = i; j < n; j++)
             if (!taken[(size_t)j] && msgs[j].code_k == msgs[i].code_k && msgs[j].code_m == msgs[i].code_m) { idx.push_back(j); taken[(size_t)j] = 1; }
-        const int K = (int)msgs[i].code_k, M = (int)msgs[i].code_m, N = K + M;
-        const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
-        recon_entry *e;
-        if ((rc = get_entry(r, K, M, &e))) return rc;
         for (size_t at = 0; at < idx.size(); at += (size_t)r->cfg.max_blocks) {
             const int m = (int)std::min(idx.size() - at, (size_t)r->cfg.max_blocks);
-            std::vector<uint32_t> info((size_t)m * Wk, 0u), cw((size_t)m * Wn);
-            for (int t = 0; t < m; t++) {
-                const int j = idx[at + (size_t)t], kb = key_bits[j], Wkey = (kb + 31) / 32;
-                uint32_t *f = info.data() + (size_t)t * Wk;
-                memcpy(f, key_words[j], sizeof(uint32_t) * (size_t)Wkey);
-                if (kb & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (kb & 31));
-            }
-            HIPCHK(hipMemcpy(e->d_bits, info.data(), sizeof(uint32_t) * info.size(), hipMemcpyHostToDevice));
-            if ((rc = qldpc_encode_packed_dev(e->enc, e->d_bits, e->d_out, m, nullptr))) return rc;
-            HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemcpy(cw.data(), e->d_out, sizeof(uint32_t) * cw.size(), hipMemcpyDeviceToHost));
-            for (int t = 0; t < m; t++) {
-                const int j = idx[at + (size_t)t];
-                memset(parity_words[j], 0, sizeof(uint32_t) * (size_t)Wm);
-                memcpy(parity_words[j], cw.data() + (size_t)t * Wn + Wk, sizeof(uint32_t) * (size_t)(Wn - Wk));
-                msgs[j].crc32 = qldpc_crc32_words(key_words[j], key_bits[j]);
-            }
+            std::vector<const uint32_t *> k((size_t)m);
+            std::vector<uint32_t *> p((size_t)m);
+            std::vector<qldpc_recon_msg *> mm((size_t)m);
+            std::vector<int> kb((size_t)m);
+            for (int t = 0; t < m; t++) { const int j = idx[at + (size_t)t]; k[(size_t)t] = key_words[j]; p[(size_t)t] = parity_words[j]; mm[(size_t)t] = &msgs[j]; kb[(size_t)t] = key_bits[j]; }
+            if ((rc = encode_group(r, m, k.data(), kb.data(), mm.data(), p.data()))) return rc;
         }
     }
     return QLDPC_OK;
 }
 
-/* blocks of ONE plan (same K, M), possibly of different length: one launch.  key[i] is decoded in place. */
+extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber, qldpc_recon_msg *msg, uint32_t *parity_words, int cap)
+{
+    if (!r || !key_words || !msg || !parity_words) return QLDPC_EINVAL;
+    const uint32_t *k = key_words;
+    uint32_t *p = parity_words;
+    return qldpc_recon_encode_blocks(r, 1, &k, &key_bits, &qber, msg, &p, &cap);
+}
+
+/* blocks of ONE entry (same K, M), possibly of different length and puncturing: one launch.  key[i] is decoded in place. */
 static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *key_bits, const float *qber, const qldpc_recon_msg *const *msgs,
                         const uint32_t *const *parity, int *const *status, int *const *corrected, int *const *iterations)
 {
     const int K = (int)msgs[0]->code_k, M = (int)msgs[0]->code_m, N = K + M;
-    const int Wk = K / 32, Wn = (N + 31) / 32;
+    const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
     int rc;
     HIPCHK(hipSetDevice(r->cfg.device));
     recon_entry *e;
     if ((rc = get_entry(r, K, M, &e))) return rc;
-    if (e->cls_key_bits != K) {
-        std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* parity VNs are known; key VNs past a block's length are pinned per frame */
-        for (int i = 0; i < K; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
-        HIPCHK(hipMemcpy(e->d_cls, cls.data(), (size_t)N, hipMemcpyHostToDevice));
-        e->cls_key_bits = K;
-    }
-    std::vector<uint32_t> frame((size_t)n * Wn, 0u), outw((size_t)n * Wn);
+    std::vector<uint32_t> keys((size_t)n * Wk, 0u), disc((size_t)n * Wm, 0u), outw((size_t)n * Wn);
     std::vector<float> mag((size_t)n);
+    std::vector<int> np((size_t)n);
+    bool any_punct = false;
     for (int i = 0; i < n; i++) {
         const int Wkey = (key_bits[i] + 31) / 32;
-        uint32_t *f = frame.data() + (size_t)i * Wn;
-        memcpy(f, key[i], sizeof(uint32_t) * (size_t)Wkey);
-        if (key_bits[i] & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (key_bits[i] & 31));
-        memcpy(f + Wk, parity[i], sizeof(uint32_t) * (size_t)(Wn - Wk));
-        mag[(size_t)i] = qldpc_bsc_llr(qber[i]);
+        memcpy(keys.data() + (size_t)i * Wk, key[i], sizeof(uint32_t) * (size_t)Wkey);
+        np[(size_t)i] = (int)msgs[i]->n_punct;
+        any_punct = any_punct || np[(size_t)i] != 0;
+        memcpy(disc.data() + (size_t)i * Wm, parity[i], sizeof(uint32_t) * (size_t)((M - np[(size_t)i] + 31) / 32));
+        mag[(size_t)i] = qldpc_bsc_llr(clamp_qber(qber[i]));
     }
-    HIPCHK(hipMemcpy(e->d_bits, frame.data(), sizeof(uint32_t) * frame.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_key, keys.data(), sizeof(uint32_t) * keys.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_disc, disc.data(), sizeof(uint32_t) * disc.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_mag, mag.data(), sizeof(float) * mag.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_nch, key_bits, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_np, np.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rk_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n), dim3(256), 0, 0, e->d_key, e->d_disc, e->d_nch, e->d_np, e->d_bits, e->d_erase, Wk, Wn, Wm, M);
+    HIPCHK(hipGetLastError());
     if ((rc = qldpc_load_bits_short_dev(e->dec, e->d_bits, e->d_mag, e->d_cls, e->d_nch, n))) return rc;
+    if (any_punct && (rc = qldpc_load_erasures_dev(e->dec, e->d_erase, n))) return rc;
     if ((rc = qldpc_run(e->dec))) return rc;
     if ((rc = qldpc_fetch_packed_dev(e->dec, e->d_out))) return rc;
     if ((rc = qldpc_fetch_status_dev(e->dec, e->d_iters, e->d_ok))) return rc;
@@ -334,22 +490,25 @@ static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *
 }
 
 /*
- * Blocks of any mix of lengths and plans in one call ("let many blocks queue and decode in one
- * launch"): blocks are grouped by plan (code_k, code_m) and every group goes through the decoder in launches of up to
- * max_blocks frames; within a group the blocks may differ in length (their unused key VNs are pinned per frame).
+ * Blocks of any mix of lengths, rates and puncturing in one call ("let many blocks queue and decode in one
+ * launch"): blocks are grouped by code (code_k, code_m) and every group goes through the decoder in launches of up to max_blocks
+ * frames; within a group the blocks may differ in length (shortening per frame) and in efficiency (puncturing per frame).
+ * Every message is validated on its own: status[i] = QLDPC_OK | QLDPC_EDECODE | QLDPC_ESIZE (header does not match the block /
+ * the local plan -- that block is not decoded, the others are).
  */
 extern "C" int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const *key_words, const int *key_bits, const float *qber,
                                          const qldpc_recon_msg *msgs, const uint32_t *const *parity_words, int *status, int *corrected, int *iterations)
 {
     if (!r || !key_words || !key_bits || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
     int rc;
+    std::vector<char> taken((size_t)n, 0);
     for (int i = 0; i < n; i++) {
         if (!key_words[i] || !parity_words[i]) return QLDPC_EINVAL;
-        if ((rc = check_msg(r, &msgs[i], key_bits[i]))) return rc;
-        if (!(qber[i] > 0.0f && qber[i] < 0.5f)) { qldpc_set_error("recon_decode_blocks: qber[%d]=%g", i, (double)qber[i]); return QLDPC_EINVAL; }
         status[i] = QLDPC_EDECODE;
+        if (corrected) corrected[i] = 0;
+        if (iterations) iterations[i] = 0;
+        if (check_msg(r, &msgs[i], key_bits[i]) || !(qber[i] >= 0.0f && qber[i] < 0.5f)) { status[i] = QLDPC_ESIZE; taken[(size_t)i] = 1; }
     }
-    std::vector<char> taken((size_t)n, 0);
     for (int i = 0; i < n; i++) {
         if (taken[(size_t)i]) continue;
         std::vector<int> idx;
@@ -374,14 +533,13 @@ extern "C" int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const 
     return QLDPC_OK;
 }
 
-/* n blocks of ONE plan and length, contiguous arrays (the config-3 stream driver's call) */
+/* n blocks of ONE length, contiguous arrays (the config-3 stream driver's call); parity_words rows are ceil(code_m / 32) words apart */
 extern "C" int qldpc_recon_decode_batch(qldpc_recon *r, int n, uint32_t *key_words, int key_bits, const float *qber, const qldpc_recon_msg *msgs,
                                         const uint32_t *parity_words, int *status, int *corrected, int *iterations)
 {
     if (!r || !key_words || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
-    if (n > r->cfg.max_blocks) { qldpc_set_error("recon_decode_batch: %d blocks > max_blocks %d", n, r->cfg.max_blocks); return QLDPC_ESIZE; }
     for (int i = 0; i < n; i++)
-        if (msgs[i].code_k != msgs[0].code_k || msgs[i].code_m != msgs[0].code_m) { qldpc_set_error("recon_decode_batch: block %d has a different plan", i); return QLDPC_ESIZE; }
+        if (msgs[i].code_k != msgs[0].code_k || msgs[i].code_m != msgs[0].code_m) { qldpc_set_error("recon_decode_batch: block %d has a different code", i); return QLDPC_ESIZE; }
     const int Wkey = (key_bits + 31) / 32, Wm = ((int)msgs[0].code_m + 31) / 32;
     std::vector<uint32_t *> k((size_t)n);
     std::vector<const uint32_t *> p((size_t)n);
@@ -399,7 +557,7 @@ extern "C" int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_b
     if (rc) return rc;
     if (corrected) *corrected = corr;
     if (iterations) *iterations = it;
-    if (leaked) *leaked = (int)msg->code_m + 32;      /* disclosed parity bits + the CRC */
-    if (status != QLDPC_OK) qldpc_set_error("recon_decode: no verified codeword after %d iterations", it);
+    if (leaked) *leaked = qldpc_recon_leaked_bits(msg);      /* disclosed parity bits + the CRC */
+    if (status == QLDPC_EDECODE) qldpc_set_error("recon_decode: no verified codeword after %d iterations", it);
     return status;
 }

@@ -416,3 +416,63 @@ def test_generated_qc_peg_code_decodes_bit_exact(q, O, torch):
         hard, it, ok, _ = staged(q, torch, dec, llr, want_post=False)
         assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
         assert ok.mean() > 0.9 and (hard[ok == 1] == 0).all()
+
+
+@pytest.mark.parametrize("variant", ["frames-bits", "frames-llr", "frames-f16", "frames-i8", "edges", "hlayered", "frames-bits-compact"])
+def test_per_frame_erasures(q, O, torch, variant):
+    """qldpc_load_erasures_dev: the harness's `LLRs[pattern[i]] = 0` (BS/src/main.cpp:359-362) with a pattern per frame -- every
+    engine, message width and LLR form must give what the oracle gives on LLRs with those entries zeroed."""
+    rng = np.random.default_rng(21)
+    code = q.Code.ira(2048, 1536, 0.2, 8, 3, 11)
+    var, chk = code.edges()
+    og = O.Graph.from_edges(code.N, code.M, var, chk)
+    N, K = code.N, 1536
+    F = 8 if variant == "edges" else 330
+    enc = q.Encoder(code, "IRA")
+    info = rng.integers(0, 2, (F, K)).astype(np.uint8)
+    cw = q.unpack_bits(enc.encode_packed(torch.from_numpy(q.pack_bits(info).view(np.int32)).cuda()).cpu().numpy().view(np.uint32), N)
+    qber = rng.uniform(0.005, 0.03, F).astype(np.float32)
+    y = cw.copy()
+    y[:, :K] ^= (rng.random((F, K)) < qber[:, None]).astype(np.uint8)
+    mag = np.array([q.bsc_llr(float(p)) for p in qber], np.float32)
+    cls = np.zeros(N, np.uint8)
+    cls[K:] = q.VN_PINNED
+    erase = np.zeros((F, N), np.uint8)
+    for f in range(F):                                            # a different number of evenly spaced punctured parity VNs per frame
+        p = int(rng.integers(0, 200))
+        j = np.arange(N - K, dtype=np.int64)
+        erase[f, K:] = ((j + 1) * p // (N - K) > j * p // (N - K))
+    llr = np.where(y == 1, -mag[:, None], mag[:, None]).astype(np.float32)
+    llr[:, K:] = np.where(cw[:, K:] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))
+    llr[erase == 1] = 0.0
+    kw = dict(rule="NMS", rule_param=0.75, n_frames=F)
+    okw = {}
+    sched = "flooding"
+    if variant == "frames-f16":
+        kw["msg_dtype"] = "f16"; okw["msg_fp16"] = True
+    if variant == "frames-i8":
+        kw["msg_dtype"] = "i8"; okw["msg_i8"] = True
+    if variant == "edges":
+        kw["engine"] = "edges"
+    if variant == "frames-bits-compact":
+        kw["compact"] = "on"
+    g2 = og
+    if variant == "hlayered":
+        sched = "hlayered"; kw["schedule"] = "hlayered"
+        order, _, _ = code.layer_order()
+        inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+        g2 = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    ref = O.decode(g2, llr, "NMS", 0.75, 30, sched, True, 1, n_threads=8, **okw)
+    dec = q.Decoder(code, N, 30, **kw)
+    if variant == "frames-llr":
+        clean = llr.copy()
+        clean[erase == 1] = np.where(cw[erase == 1] == 1, -np.float32(q.CONFIRMED_BIT_LLR), np.float32(q.CONFIRMED_BIT_LLR))      # un-erased; the erasure comes from the call
+        dec.load_llr(torch.from_numpy(clean).cuda())
+    else:
+        dec.load_bits(torch.from_numpy(q.pack_bits(y).view(np.int32)).cuda(), torch.from_numpy(mag).cuda(), torch.from_numpy(cls).cuda())
+    dec.load_erasures(torch.from_numpy(q.pack_bits(erase).view(np.int32)).cuda())
+    dec.run()
+    hard = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), N)
+    it, ok = dec.fetch_status()
+    assert (hard == ref["hard"]).all() and (it.cpu().numpy() == ref["iters"]).all() and (ok.cpu().numpy() == ref["synd_ok"]).all()
+    assert (ref["synd_ok"] == 1).mean() > 0.5

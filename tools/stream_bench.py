@@ -40,7 +40,7 @@ t_enc = time.perf_counter() - t0
 # warm the per-plan decoder cache
 for key, idx in groups.items():
     j = idx[:1]
-    rb.decode_batch(bw[j], KEY_BITS, qbers[j], [msgs[j[0]]], np.stack([pars[j[0]]]))
+    rb.decode_batch(bw[j], KEY_BITS, qbers[j], [msgs[j[0]]], [pars[j[0]]])
 
 t0 = time.perf_counter()
 ok = np.zeros(EPOCHS, bool)
@@ -48,13 +48,13 @@ iters = np.zeros(EPOCHS, int)
 for key, idx in groups.items():
     for lo in range(0, len(idx), BATCH):
         j = idx[lo:lo + BATCH]
-        st, fixed, co, it = rb.decode_batch(bw[j], KEY_BITS, qbers[j], [msgs[k] for k in j], np.stack([pars[k] for k in j]))
+        st, fixed, co, it = rb.decode_batch(bw[j], KEY_BITS, qbers[j], [msgs[k] for k in j], [pars[k] for k in j])
         good = st == 0
         ok[j] = good
         iters[j] = it
         assert (fixed[good] == aw[j][good]).all()
 dt = time.perf_counter() - t0
-leak = sum(plans[i].code_m + 32 for i in range(EPOCHS) if ok[i])
+leak = sum(q.Recon.leaked_bits(msgs[i]) for i in range(EPOCHS) if ok[i])
 print("config 3 stream: %d epochs x %d bits, QBER U[0.5%%, 6%%], batch <= %d, Bob decodes %s" % (EPOCHS, KEY_BITS, BATCH, SCHED))
 for key, idx in sorted(groups.items()):
     print("  rate %.1f (K %d, M %d): %3d epochs, %3d reconciled, mean iterations %.1f" % (ra.rates[key[0]], key[1], key[2], len(idx), int(ok[idx].sum()), iters[idx].mean()))
