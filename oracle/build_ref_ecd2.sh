@@ -5,8 +5,10 @@
 #   oracle/_ref/ecd2_cascade  pristine reference daemon (cascade_biconf): the integration oracle of SURVEY.md section 4
 #   oracle/_ref/ecd2_ldpc     the same sources with the four maintainer edits of INTEGRATION.md section 2 applied to a
 #                             scratch copy (the two `return 81` arms of subcomponents/qber_estim.c:337-340,420-423, the
-#                             algorithm choice at :301 made switchable with ECD2_LDPC=1, four appended error messages, the
-#                             ldpc_tick() call + ldpc_pending() time-out term in ecd2.c's main loop for batched ingest) and
+#                             algorithm choice at :301 taken from the new `-L` option (ldpc_selected(); ECD2_LDPC=1 still works),
+#                             `L:` added to ecd2.c:26's getopt string, ldpc_init() before the main loop when LDPC is selected, four
+#                             appended error messages, the ldpc_tick() call + ldpc_pending() time-out term in ecd2.c's main loop
+#                             for batched ingest, MAX_BITS_PER_PROCESSBLOCK / TEMP_ARRAY_SIZE raised to 2^18 bits for the LDPC path) and
 #                             linked with qcrypto-ldpc_amd/host/ldpc_reconcile.c + libqldpc.so
 # Nothing from /root/reference is copied into the repository; the scratch copy lives in a temp dir and is deleted.
 set -euo pipefail
@@ -32,7 +34,7 @@ p = "subcomponents/qber_estim.c"
 s = open(p).read()
 s = s.replace('#include "qber_estim.h"', '#include "qber_estim.h"\n#include "ldpc_reconcile.h"\n#include <stdlib.h>', 1)
 s = s.replace("chosenAlgorithm = ALG_CASCADE_CONTINUE_ROLES;",
-              'chosenAlgorithm = getenv("ECD2_LDPC") ? ALG_LDPC_CONTINUE_ROLES : ALG_CASCADE_CONTINUE_ROLES;', 1)
+              'chosenAlgorithm = ldpc_selected() ? ALG_LDPC_CONTINUE_ROLES : ALG_CASCADE_CONTINUE_ROLES;', 1)
 arm = "    case ALG_LDPC_CONTINUE_ROLES:\n      return 81;\n    case ALG_LDPC_FLIP_ROLES:\n      return 81;\n"
 assert s.count(arm) == 2, s.count(arm)
 first = s.index(arm)
@@ -51,10 +53,10 @@ loop = ("    for (i = 0; i < pb->finalKeyBits; i++) { /* go through all targetbi
         "      if (calcParity(m)) finalkey[wordIndex(i)] |= uint32AllZeroExceptAtN(i);\n"
         "    }\n")
 assert s.count(loop) == 1
-s = s.replace(loop, "    if (getenv(\"ECD2_GPU_PA\")) {\n"
+s = s.replace(loop, "    if (ldpc_gpuPrivAmp()) {\n"
                     "      if (qldpc_privamp(0, pb->mainBufPtr, pb->workbits, seed, pb->finalKeyBits, finalkey)) return 85;\n"
                     "    } else {\n" + loop + "    }\n", 1)
-s = s.replace('#include "priv_amp.h"', '#include "priv_amp.h"\n#include "qldpc.h"\n#include <stdlib.h>', 1)
+s = s.replace('#include "priv_amp.h"', '#include "priv_amp.h"\n#include "ldpc_reconcile.h"\n#include <stdlib.h>', 1)
 open(p, "w").write(s)
 p = "ecd2.c"
 s = open(p).read()
@@ -64,9 +66,27 @@ tail = ("      free2(tmpRecvdPktNode);                            /* ...and poin
 assert s.count(tail) == 1
 s = s.replace(tail, tail + "    { int ldpcErr = ldpc_tick(receivedPacketLinkedList == NULL);      /* batched ingest: decode what queued up */\n"
                            "      if (ldpcErr) { emsg(ldpcErr); if (arguments.runtimeErrorMode == END_ON_ERR) return -ldpcErr; } }\n", 1)
+# the -L option: one more letter in the getopt string and its case, and the engine (all mother codes) brought up before the main loop
+opts = '"c:s:r:d:f:l:q:Q:e:E:kJ:T:V:Ipb:B:i"'
+assert s.count(opts) == 1
+s = s.replace(opts, '"c:s:r:d:f:l:q:Q:e:E:kJ:T:V:Ipb:B:iL:"', 1)
+case_v = "      case 'V': /* verbosity parameter */"
+assert s.count(case_v) == 1
+s = s.replace(case_v, "      case 'L': /* LDPC reconciliation options (subcomponents/ldpc_reconcile.h) */\n"
+                      "        if (ldpc_parseOption(optarg)) return -emsg(1);\n        break;\n" + case_v, 1)
+loop_head = "  // Main loop\n"
+assert s.count(loop_head) == 1
+s = s.replace(loop_head, "  if (ldpc_selected()) { int e_ = ldpc_init(0); if (e_) return -emsg(e_); }\n" + loop_head, 1)
 sel = "(cmdInput[0] || receivedPacketLinkedList) ? TENMILLISEC : HALFSECOND"
 assert s.count(sel) == 1
 s = s.replace(sel, "(cmdInput[0] || receivedPacketLinkedList || ldpc_pending()) ? TENMILLISEC : HALFSECOND", 1)
+open(p, "w").write(s)
+# blocks above 2^16 bits for the LDPC path (processblock_mgmt.c:94-95 checks against this; cascade's unsigned short indices keep their
+# limit: ldpc_reconcile.c never hands such a block to cascade)
+p = "definitions/defaultdefinitions.h"
+s = open(p).read()
+assert s.count("#define TEMP_ARRAY_SIZE (1 << 11)") == 1 and s.count("#define MAX_BITS_PER_PROCESSBLOCK (1 << 16)") == 1
+s = s.replace("#define TEMP_ARRAY_SIZE (1 << 11)", "#define TEMP_ARRAY_SIZE (1 << 13)", 1).replace("#define MAX_BITS_PER_PROCESSBLOCK (1 << 16)", "#define MAX_BITS_PER_PROCESSBLOCK (1 << 18)", 1)
 open(p, "w").write(s)
 p = "ecd2.h"
 s = open(p).read()

@@ -23,17 +23,65 @@
 static qldpc_recon *g_recon = NULL;
 static int ldpc_batchSize(void);
 
+/* ---- options: the daemon's -L letter (ecd2.c:26), with the environment as the fall-back for unmodified command lines ---------- */
+static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0;
+static int g_batch = -1, g_wait_ms = -1;
+
+static int ldpc_envInt(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+int ldpc_parseOption(const char *optarg)
+{
+    const char *p = optarg;
+    if (!p) return 1;
+    while (*p) {
+        char *end;
+        switch (*p) {
+        case '0': g_opt_select = 0; end = (char *)p + 1; break;
+        case '1': g_opt_select = 1; end = (char *)p + 1; break;
+        case 'g': g_opt_gpu_pa = 1; end = (char *)p + 1; break;
+        case 'b': g_batch = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_batch < 1) return 1; break;
+        case 'w': g_wait_ms = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_wait_ms < 0) return 1; break;
+        case 'f': g_opt_fallback = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;
+        case 'p': g_opt_max_packet = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_max_packet < 256) return 1; break;
+        case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* fault injection (tests): flip n disclosed parity bits */
+        case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* fault injection (tests): send every parity packet n more times */
+        default: return 1;
+        }
+        p = end;
+        if (*p == ',') p++;
+        else if (*p) return 1;
+    }
+    return 0;
+}
+
+int ldpc_selected(void) { return g_opt_select >= 0 ? g_opt_select : (getenv("ECD2_LDPC") != NULL); }
+int ldpc_gpuPrivAmp(void) { return g_opt_gpu_pa >= 0 ? g_opt_gpu_pa : (getenv("ECD2_GPU_PA") != NULL); }
+static int ldpc_maxPacketBytes(void)
+{
+    int v = g_opt_max_packet >= 0 ? g_opt_max_packet : ldpc_envInt("ECD2_LDPC_MAX_PACKET", LDPC_MAX_PACKET_BYTES);
+    if (v > LDPC_MAX_PACKET_BYTES) v = LDPC_MAX_PACKET_BYTES;
+    if (v < (int)sizeof(EcPktHdr_LdpcParity) + 64) v = (int)sizeof(EcPktHdr_LdpcParity) + 64;
+    return v;
+}
+
 int ldpc_init(int device)
 {
     qldpc_recon_cfg cfg;
     if (g_recon) return 0;
     qldpc_recon_cfg_default(&cfg);
     cfg.device = device;
+    cfg.preload = 1;                   /* every mother code / encoder / decoder now: no construction, no device allocation per block */
     cfg.max_blocks = ldpc_batchSize();
     if (qldpc_recon_create(&cfg, &g_recon) != QLDPC_OK) {
         fprintf(stderr, "ldpc_init: %s\n", qldpc_last_error());
         return LDPC_ERR_ENGINE;
     }
+    printf("ldpc: engine ready, %ld code / encoder / decoder sets built, up to %d blocks per decode call\n", qldpc_recon_entries_created(g_recon), cfg.max_blocks);
+    fflush(stdout);
     return 0;
 }
 
@@ -56,6 +104,8 @@ static int initLdpcData(ProcessBlock *processBlock)
 
 static int freeLdpcData(ProcessBlock *processBlock)
 {
+    LdpcData *ld = (LdpcData *)processBlock->algorithmDataPtr;
+    if (ld && ld->parityWords) free2(ld->parityWords);
     free2(processBlock->algorithmDataPtr);
     processBlock->algorithmDataPtr = NULL;
     processBlock->algorithmDataMngr = NULL;
@@ -116,9 +166,11 @@ static int ldpc_setup(ProcessBlock *pb, PROCESSOR_ROLE role)
  * leakageBits, so privacy amplification accounts for both attempts.  ECD2_LDPC_FALLBACK=0 restores "drop". */
 static int ldpc_fallbackEnabled(void)
 {
-    const char *e = getenv("ECD2_LDPC_FALLBACK");
-    return !(e && e[0] == '0');
+    return g_opt_fallback >= 0 ? g_opt_fallback != 0 : ldpc_envInt("ECD2_LDPC_FALLBACK", 1) != 0;
 }
+/* cascade keeps its permutations in unsigned short indices (definitions/processblock.h:126-127): a block above 2^16 - 1 bits, which
+ * only the LDPC path can take (MAX_BITS_PER_PROCESSBLOCK raised for it), cannot be handed over */
+static int ldpc_canFallBack(const ProcessBlock *pb) { return ldpc_fallbackEnabled() && pb->initialBits < (1 << 16); }
 
 /* cascade begins with helper_cleanupRevealedBits once more (helper_prepPermutationWrapper, helpers.c:79-82), which
  * (a) would overwrite the already compacted key at the marked positions and (b) zeroes leakageBits.  (a): rewrite the
@@ -215,55 +267,96 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
 {
     LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
     qldpc_recon_msg msg;
-    EcPktHdr_LdpcParity *h9;
-    unsigned int parityWords, totalBytes;
-    int rc, errorCode;
+    uint32_t *parity;
+    unsigned int parityWords, perPacket, fragCount, f;
+    int rc, errorCode = 0;
 
     rc = qldpc_recon_plan(g_recon, pb->workbits, pb->localError, &msg);
     if (rc == QLDPC_EUNSUPPORTED) return LDPC_ERR_RATE;
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
-    parityWords = (msg.code_m + 31) / 32;
-    totalBytes = sizeof(EcPktHdr_LdpcParity) + parityWords * WORD_SIZE;
-    if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, totalBytes, pb))) return errorCode;
-
-    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (uint32_t *)&h9[1], (int)parityWords);
-    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(h9); return LDPC_ERR_ENGINE; }
-    h9->rateIndex = msg.rate_index;
-    h9->keyBits = msg.key_bits;
-    h9->codeK = msg.code_k;
-    h9->codeM = msg.code_m;
-    h9->crc32 = msg.crc32;
-    {   /* fault injection for tests of the fallback path: ECD2_LDPC_FAULT=n flips n disclosed parity bits */
-        const char *fault = getenv("ECD2_LDPC_FAULT");
-        int n = fault ? atoi(fault) : 0, i;
-        for (i = 0; i < n && i < (int)msg.code_m; i++) {
-            const int pos = i * 97 % (int)msg.code_m;
-            ((uint32_t *)&h9[1])[pos / 32] ^= 1u << (31 - pos % 32);
+    parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
+    parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
+    if (!parity) return 43;
+    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, parity, (int)parityWords);
+    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
+    {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits */
+        const int n = g_opt_fault >= 0 ? g_opt_fault : ldpc_envInt("ECD2_LDPC_FAULT", 0), disclosed = (int)(msg.code_m - msg.n_punct);
+        int i;
+        for (i = 0; i < n && i < disclosed; i++) {
+            const int pos = i * 97 % disclosed;
+            parity[pos / 32] ^= 1u << (31 - pos % 32);
         }
     }
+    /* one packet if it fits under transferd's cap, else consecutive slices with the same header */
+    perPacket = ((unsigned int)ldpc_maxPacketBytes() - sizeof(EcPktHdr_LdpcParity)) / WORD_SIZE;
+    fragCount = (parityWords + perPacket - 1) / perPacket;
+    if (fragCount < 1) fragCount = 1;
+    if (fragCount > LDPC_MAX_FRAGMENTS) { free2(parity); return LDPC_ERR_PKT_SIZE; }
+    for (f = 0; f < fragCount && !errorCode; f++) {
+        const unsigned int off = f * perPacket, words = (parityWords - off < perPacket) ? parityWords - off : perPacket;
+        EcPktHdr_LdpcParity *h9;
+        if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE, pb))) break;
+        h9->rateIndex = msg.rate_index; h9->keyBits = msg.key_bits; h9->codeK = msg.code_k; h9->codeM = msg.code_m;
+        h9->crc32 = msg.crc32; h9->nPunct = msg.n_punct;
+        h9->fragIndex = f; h9->fragCount = fragCount; h9->fragWordOffset = off;
+        memcpy(&h9[1], parity + off, words * WORD_SIZE);
+        {
+            int d;
+            for (d = 0; d < g_opt_dup && !errorCode; d++) {      /* tests only: the same packet again */
+                char *copy = malloc2(h9->base.totalLengthInBytes);
+                if (!copy) { errorCode = 43; break; }
+                memcpy(copy, h9, h9->base.totalLengthInBytes);
+                errorCode = comms_insertSendPacket(copy, h9->base.totalLengthInBytes);
+            }
+        }
+        if (!errorCode) errorCode = comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
+        else free2(h9);
+    }
+    free2(parity);
+    if (errorCode) return errorCode;
     ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m;
-
     pb->processingState = PSTATE_PERFORMED_PARITY;
-    pb->leakageBits += (int)msg.code_m + 32;            /* disclosed parity bits + CRC */
-    printf("ldpc: epoch %08x: sent parity, %d key bits, rate index %u, K %u, M %u\n", pb->startEpoch, pb->workbits, msg.rate_index, msg.code_k, msg.code_m);
+    pb->leakageBits += qldpc_recon_leaked_bits(&msg);            /* disclosed parity bits + CRC */
+    printf("ldpc: epoch %08x: sent parity in %u packet(s), %d key bits, rate index %u, K %u, M %u, %u punctured, %d bits disclosed\n", pb->startEpoch, fragCount,
+           pb->workbits, msg.rate_index, msg.code_k, msg.code_m, msg.n_punct, qldpc_recon_leaked_bits(&msg));
     fflush(stdout);
-    return comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
+    return 0;
 }
 
 /* ---- EC follower ("Bob"): decode, verify, verdict, privacy amplification --------------------- */
 
-static int ldpc_parseParity(ProcessBlock *pb, const char *receivebuf, qldpc_recon_msg *msg)
+/* one fragment of a block's parity: validate it against the block and against the fragments seen so far, copy its words.
+ * returns 0 and *complete = 1 once every fragment is there; a packet for a block that is not waiting for parity (a duplicate after
+ * completion, a packet for the wrong role) is ignored (*complete = 0). */
+static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *complete)
 {
-    const EcPktHdr_LdpcParity *in_head = (const EcPktHdr_LdpcParity *)receivebuf;
-    const unsigned int parityWords = (in_head->codeM + 31) / 32;
-    if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + parityWords * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
-    if ((int)in_head->keyBits != pb->workbits) return LDPC_ERR_PKT_SIZE;
-    memset(msg, 0, sizeof(*msg));
-    msg->rate_index = in_head->rateIndex;
-    msg->key_bits = in_head->keyBits;
-    msg->code_k = in_head->codeK;
-    msg->code_m = in_head->codeM;
-    msg->crc32 = in_head->crc32;
+    const EcPktHdr_LdpcParity *in = (const EcPktHdr_LdpcParity *)receivebuf;
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    unsigned int totalWords, words;
+    *complete = 0;
+    if (pb->processorRole != PROC_ROLE_EC_FOLLOWER || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !ld) return LDPC_ERR_PKT_SIZE;
+    if (ld->parityState != 0) return 0;                              /* already complete (queued or decoding): a repeated packet */
+    if (in->base.totalLengthInBytes < sizeof(EcPktHdr_LdpcParity) || in->base.totalLengthInBytes > LDPC_MAX_PACKET_BYTES) return LDPC_ERR_PKT_SIZE;
+    if ((int)in->keyBits != pb->workbits || in->nPunct > in->codeM || in->codeM > (1u << 26)) return LDPC_ERR_PKT_SIZE;
+    if (in->fragCount < 1 || in->fragCount > LDPC_MAX_FRAGMENTS || in->fragIndex >= in->fragCount) return LDPC_ERR_PKT_SIZE;
+    totalWords = (in->codeM - in->nPunct + 31) / 32;
+    words = (in->base.totalLengthInBytes - sizeof(EcPktHdr_LdpcParity)) / WORD_SIZE;
+    if (in->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
+    if (in->fragWordOffset > totalWords || words > totalWords - in->fragWordOffset) return LDPC_ERR_PKT_SIZE;
+    if (!ld->parityWords) {
+        ld->parityWords = (unsigned int *)malloc2(totalWords * WORD_SIZE + WORD_SIZE);
+        if (!ld->parityWords) return 43;
+        memset(ld->parityWords, 0, totalWords * WORD_SIZE + WORD_SIZE);
+        memset(&ld->msg, 0, sizeof(ld->msg));
+        ld->msg.rate_index = in->rateIndex; ld->msg.key_bits = in->keyBits; ld->msg.code_k = in->codeK; ld->msg.code_m = in->codeM;
+        ld->msg.crc32 = in->crc32; ld->msg.n_punct = in->nPunct;
+        ld->fragCount = in->fragCount; ld->fragsSeen = 0;
+    } else if (ld->msg.rate_index != in->rateIndex || ld->msg.code_k != in->codeK || ld->msg.code_m != in->codeM || ld->msg.crc32 != in->crc32 ||
+               ld->msg.n_punct != in->nPunct || ld->fragCount != in->fragCount) return LDPC_ERR_PKT_SIZE;      /* fragments must agree */
+    if (ld->fragsSeen & (1u << in->fragIndex)) return 0;             /* this fragment again */
+    memcpy(ld->parityWords + in->fragWordOffset, receivebuf + sizeof(EcPktHdr_LdpcParity), words * WORD_SIZE);
+    ld->fragsSeen |= 1u << in->fragIndex;
+    if (ld->fragsSeen == (ld->fragCount >= 32 ? 0xFFFFFFFFu : (1u << ld->fragCount) - 1u)) { ld->parityState = 1; *complete = 1; }
     return 0;
 }
 
@@ -272,7 +365,7 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
 {
     LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
     EcPktHdr_LdpcVerdict *h10;
-    const int leaked = (int)msg->code_m + 32;            /* disclosed parity bits + the CRC */
+    const int leaked = qldpc_recon_leaked_bits(msg);     /* disclosed parity bits + the CRC */
     int errorCode;
 
     if ((errorCode = ldpc_createHeader((char **)&h10, SUBTYPE_LDPC_VERDICT, sizeof(EcPktHdr_LdpcVerdict), pb))) return errorCode;
@@ -285,7 +378,7 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
         /* no codeword found or CRC mismatch: mainBufPtr is untouched, the disclosed bits are spent */
         printf("ldpc: epoch %08x: no verified codeword after %d iterations\n", pb->startEpoch, iterations);
         pb->leakageBits += leaked;
-        if (ldpc_fallbackEnabled()) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_FOLLOWER);
+        if (ldpc_canFallBack(pb)) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_FOLLOWER);
         pBlkMgmt_removeProcessBlk(pb->startEpoch);
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
@@ -306,54 +399,54 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
  * The handler owns receivebuf only until it returns (ecd2.c:546-548), so the packet is copied.
  */
 #define LDPC_BATCH_MAX 64
-static struct { unsigned int epoch; char *packet; } g_queue[LDPC_BATCH_MAX];
-static int g_queued = 0, g_batch = -1, g_wait_ms = 0;
+static unsigned int g_queue[LDPC_BATCH_MAX];      /* epochs of the blocks whose parity is complete; the words live in their LdpcData */
+static int g_queued = 0;
 static struct timespec g_first;
 
 static int ldpc_batchSize(void)
 {
-    if (g_batch < 0) {
-        const char *e = getenv("ECD2_LDPC_BATCH"), *w = getenv("ECD2_LDPC_BATCH_WAIT_MS");
-        g_batch = e ? atoi(e) : 1;
-        if (g_batch < 1) g_batch = 1;
-        if (g_batch > LDPC_BATCH_MAX) g_batch = LDPC_BATCH_MAX;
-        g_wait_ms = w ? atoi(w) : 0;
-    }
+    if (g_batch < 0) g_batch = ldpc_envInt("ECD2_LDPC_BATCH", 1);
+    if (g_wait_ms < 0) g_wait_ms = ldpc_envInt("ECD2_LDPC_BATCH_WAIT_MS", 0);
+    if (g_batch < 1) g_batch = 1;
+    if (g_batch > LDPC_BATCH_MAX) g_batch = LDPC_BATCH_MAX;
     return g_batch;
 }
 
 int ldpc_pending(void) { return g_queued; }
 
+/* decode everything queued in ONE qldpc_recon_decode_blocks call.  Every block is looked up by epoch again (it may have been removed
+ * since it queued), validated and answered on its own: a header the engine refuses gets a failed verdict, it does not fail the batch. */
 static int ldpc_flush(void)
 {
     uint32_t *keys[LDPC_BATCH_MAX];
     const uint32_t *pars[LDPC_BATCH_MAX];
-    ProcessBlock *pbs[LDPC_BATCH_MAX];
+    unsigned int epochs[LDPC_BATCH_MAX];
     qldpc_recon_msg msgs[LDPC_BATCH_MAX];
     int bits[LDPC_BATCH_MAX], status[LDPC_BATCH_MAX], corrected[LDPC_BATCH_MAX], iterations[LDPC_BATCH_MAX];
     float qber[LDPC_BATCH_MAX];
     int n = 0, i, rc, errorCode = 0;
 
     for (i = 0; i < g_queued; i++) {
-        ProcessBlock *pb = pBlkMgmt_getProcessBlk(g_queue[i].epoch);
-        if (!pb || ldpc_parseParity(pb, g_queue[i].packet, &msgs[n])) continue;      /* block gone or packet inconsistent: drop the entry */
-        pbs[n] = pb; keys[n] = pb->mainBufPtr; bits[n] = pb->workbits; qber[n] = pb->localError;
-        pars[n] = (const uint32_t *)(g_queue[i].packet + sizeof(EcPktHdr_LdpcParity));
+        ProcessBlock *pb = pBlkMgmt_getProcessBlk(g_queue[i]);
+        LdpcData *ld;
+        if (!pb || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !(ld = (LdpcData *)pb->algorithmDataPtr) || ld->parityState != 1) continue;
+        epochs[n] = g_queue[i]; keys[n] = pb->mainBufPtr; bits[n] = pb->workbits; qber[n] = pb->localError;
+        msgs[n] = ld->msg; pars[n] = ld->parityWords;
         n++;
     }
-    if (n > 0) {
-        rc = qldpc_recon_decode_blocks(g_recon, n, keys, bits, qber, msgs, pars, status, corrected, iterations);
-        if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); errorCode = LDPC_ERR_ENGINE; }
-        else {
-            printf("ldpc: decoded a batch of %d blocks in one call\n", n);
-            for (i = 0; i < n; i++) {
-                const int e = ldpc_finishBlock(pbs[i], &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
-                if (e && !errorCode) errorCode = e;
-            }
-        }
-    }
-    for (i = 0; i < g_queued; i++) { free2(g_queue[i].packet); g_queue[i].packet = NULL; }
     g_queued = 0;
+    if (n == 0) return 0;
+    rc = qldpc_recon_decode_blocks(g_recon, n, keys, bits, qber, msgs, pars, status, corrected, iterations);
+    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
+    if (ldpc_batchSize() > 1) printf("ldpc: decoded a batch of %d blocks in one call\n", n);
+    for (i = 0; i < n; i++) {
+        ProcessBlock *pb = pBlkMgmt_getProcessBlk(epochs[i]);      /* finishing a block removes it (privacy amplification): never keep the pointer */
+        int e;
+        if (!pb) continue;
+        if (status[i] == QLDPC_ESIZE) printf("ldpc: epoch %08x: parity header refused (%s)\n", epochs[i], qldpc_last_error());
+        e = ldpc_finishBlock(pb, &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
+        if (e && !errorCode) errorCode = e;
+    }
     return errorCode;
 }
 
@@ -372,24 +465,14 @@ int ldpc_tick(int receiveQueueEmpty)
 
 int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
 {
-    EcPktHdr_LdpcParity *in_head = (EcPktHdr_LdpcParity *)receivebuf;
-    qldpc_recon_msg msg;
-    int corrected = 0, leaked = 0, iterations = 0, rc, errorCode;
-
-    if ((errorCode = ldpc_parseParity(pb, receivebuf, &msg))) return errorCode;
-    if (ldpc_batchSize() > 1) {
-        char *copy = malloc2(in_head->base.totalLengthInBytes);
-        if (!copy) return 43;
-        memcpy(copy, receivebuf, in_head->base.totalLengthInBytes);
-        if (g_queued == 0) clock_gettime(CLOCK_MONOTONIC, &g_first);
-        g_queue[g_queued].epoch = pb->startEpoch; g_queue[g_queued].packet = copy;
-        g_queued++;
-        return g_queued >= LDPC_BATCH_MAX ? ldpc_flush() : 0;      /* otherwise ldpc_tick() decides */
-    }
-    /* the handler owns receivebuf only until it returns (ecd2.c:546-548): decode straight from it */
-    rc = qldpc_recon_decode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, (const uint32_t *)&in_head[1], &corrected, &leaked, &iterations);
-    if (rc != QLDPC_OK && rc != QLDPC_EDECODE) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
-    return ldpc_finishBlock(pb, &msg, rc == QLDPC_OK, corrected, iterations);
+    int complete = 0, errorCode, i;
+    if ((errorCode = ldpc_acceptFragment(pb, receivebuf, &complete))) return errorCode;
+    if (!complete) return 0;                                         /* more fragments to come, or a packet that changes nothing */
+    for (i = 0; i < g_queued; i++) if (g_queue[i] == pb->startEpoch) return 0;
+    if (g_queued == 0) clock_gettime(CLOCK_MONOTONIC, &g_first);
+    g_queue[g_queued++] = pb->startEpoch;
+    /* one block at a time (the default): decode now, straight from the block's own buffers; with -L b<n> ldpc_tick() decides */
+    return (ldpc_batchSize() <= 1 || g_queued >= LDPC_BATCH_MAX) ? ldpc_flush() : 0;
 }
 
 /* ---- EC initiator: verdict ---------------------------------------------------------------------- */
@@ -399,7 +482,7 @@ int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
     EcPktHdr_LdpcVerdict *in_head = (EcPktHdr_LdpcVerdict *)receivebuf;
     if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) return LDPC_ERR_PKT_SIZE;
     if (!in_head->decoded) {
-        if (ldpc_fallbackEnabled()) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_INITIATOR);
+        if (ldpc_canFallBack(pb)) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_INITIATOR);
         pBlkMgmt_removeProcessBlk(pb->startEpoch);
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }

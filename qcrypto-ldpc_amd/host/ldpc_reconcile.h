@@ -30,15 +30,23 @@
 #define LDPC_ERR_DECODE_FAILED 87 /* "LDPC decoding failed, block dropped"           */
 #define LDPC_ERR_RATE 88          /* "QBER too high for the LDPC rate table"         */
 
-/** @brief subtype 9: parity message (payload = ceil(code_m/32) words, MSB-first, zero padded) */
+/** @brief subtype 9: parity message.  The payload of a block is ceil((codeM - nPunct)/32) words of disclosed parity bits,
+ *  MSB-first, zero padded; it travels in fragCount packets of at most LDPC_MAX_PACKET_BYTES each (transferd forwards packets of up
+ *  to 10 000 bytes, remotecrypto/transferd.h:139, transferd.c:850), every one with the full header and its slice of the words. */
 typedef struct ERRC_LDPC_9 {
     EcPktHdr_Base base;
     unsigned int rateIndex;       /**< index into the shared rate table                    */
     unsigned int keyBits;         /**< workbits after helper_cleanupRevealedBits           */
-    unsigned int codeK;           /**< info VNs of the code                                */
-    unsigned int codeM;           /**< parity VNs = disclosed bits                         */
+    unsigned int codeK;           /**< info VNs of the (mother) code                       */
+    unsigned int codeM;           /**< parity VNs of the code                              */
     unsigned int crc32;           /**< CRC-32 of the initiator's key                       */
+    unsigned int nPunct;          /**< parity VNs punctured: codeM - nPunct bits disclosed */
+    unsigned int fragIndex;       /**< 0 .. fragCount-1                                    */
+    unsigned int fragCount;       /**< packets this block's parity is split into (<= 32)   */
+    unsigned int fragWordOffset;  /**< first payload word of this packet in the block's parity words */
 } EcPktHdr_LdpcParity;
+#define LDPC_MAX_PACKET_BYTES 10000
+#define LDPC_MAX_FRAGMENTS 32
 
 /** @brief subtype 10: verdict */
 typedef struct ERRC_LDPC_10 {
@@ -52,14 +60,27 @@ typedef struct ERRC_LDPC_10 {
 typedef struct ALGORITHM_LDPC_DATA {
     unsigned int rateIndex, codeK, codeM;
     int iterations;
+    /* EC follower: the parity words as their fragments arrive */
+    qldpc_recon_msg msg;          /**< header of the first fragment seen (the others must repeat it) */
+    unsigned int *parityWords;    /**< malloc2'ed on the first fragment, ceil((codeM - nPunct)/32) words */
+    unsigned int fragsSeen;       /**< bit i = fragment i has arrived                                 */
+    unsigned int fragCount;
+    int parityState;              /**< 0 awaiting fragments, 1 complete and queued / being decoded   */
 } LdpcData;
 
 extern const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_INITIATOR;
 extern const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FOLLOWER;
 extern const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC;
 
-/** engine life cycle: call once from main() (device = HIP ordinal); ldpc_shutdown at exit */
+/** engine life cycle: call once from main() (device = HIP ordinal); ldpc_shutdown at exit.  Builds every mother code, encoder and
+ *  decoder (qldpc_recon_cfg.preload): nothing is constructed or allocated on the device per block afterwards. */
 int ldpc_init(int device);
+/** the daemon's `-L` option (free in ecd2.c:26's getopt string): `-L 1` = choose LDPC after QBER estimation (qber_estim.c:301),
+ *  `-L b<n>` batch size of the batched ingest, `-L w<ms>` its wait, `-L g` privacy amplification on the GPU, `-L f0` no cascade
+ *  fallback, `-L p<bytes>` largest parity packet; several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
+int ldpc_parseOption(const char *optarg);
+int ldpc_selected(void);          /**< 1 after `-L 1` (or ECD2_LDPC=1 in the environment) */
+int ldpc_gpuPrivAmp(void);        /**< 1 after `-L g` (or ECD2_GPU_PA=1)                   */
 void ldpc_shutdown(void);
 
 /** batched ingest (ECD2_LDPC_BATCH=n): call ldpc_tick(receivedPacketLinkedList == NULL) once per main-loop iteration (ecd2.c, after

@@ -30,7 +30,8 @@ def read_stream7(path):
     return dict(tag=tag, epoch=epoch, nepochs=nepochs, nbits=nbits, words=words)
 
 
-def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180, blocks=None, cmd_gaps=(60.0, 0.25)):
+def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_extra=None, timeout=180, blocks=None, cmd_gaps=(60.0, 0.25), extra_args=None,
+                 extra_args_a=None, extra_args_b=None):
     """alice_bits / bob_bits: lists of per-epoch 0/1 arrays. Returns dict with both final keys + logs.
     blocks: epochs per command (default: one command = one block of all epochs); with several commands written at once
     several blocks are in flight, and out["finals"] maps each block's first epoch to its (alice, bob) stream-7 files."""
@@ -51,7 +52,8 @@ def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_e
 
     def daemon(side, send, recv):
         args = [binary, "-c", side + "_cmd", "-s", send, "-r", recv, "-d", side + "/raw", "-f", side + "/final",
-                "-l", side + "/notify", "-q", side + "/resp", "-Q", side + "_q", "-V", "5"]
+                "-l", side + "/notify", "-q", side + "/resp", "-Q", side + "_q", "-V", "5"] + list(extra_args or []) + \
+            list((extra_args_a if side == "a" else extra_args_b) or [])
         log = open(os.path.join(d, side + ".log"), "w")
         return subprocess.Popen(args, cwd=d, env=env, stdout=log, stderr=subprocess.STDOUT), log
 

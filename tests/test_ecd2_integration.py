@@ -53,9 +53,15 @@ def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
     a, b = epochs(1, 4, 4001, 0.02)
     out = run_loopback(binary, tmp_path / "try1", a, b, timeout=60)
     if out["a_final"] is None or out["b_final"] is None:
-        # two real-time daemons of the reference talking over FIFOs: seen to stall once in ~20 runs on a loaded machine
-        # (one daemon exits early); the pristine reference is the oracle here, not the unit under test -- try once more
+        # The pristine reference is the oracle here, not the unit under test.  A second attempt is allowed ONLY when the first one
+        # shows one of the reference's own diagnosed ways of giving up on a block: the QBER sample drawn
+        # from /dev/urandom asked to terminate it (REPLYMODE_TERMINATE: too few / too many errors in the first 411 bits,
+        # qber_estim.c:28-36) or the sample positions fell out of step (error 80, comms.c:80 / qber_estim.c:190).  Anything else
+        # -- a silent stall, a crash -- fails the test.
+        logs = out["a_log"] + out["b_log"]
+        known = ("Reply mode out of bounds" in logs) or ("erminat" in logs) or ("error 80" in logs) or ("Error 80" in logs)
         print("first attempt failed:\n" + out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:])
+        assert known, "reference cascade loopback failed without one of its diagnosed signatures"
         out = run_loopback(binary, tmp_path / "try2", a, b, timeout=120)
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + out["b_log"][-2000:]
     assert out["a_final"]["tag"] == 7 and out["a_final"]["nbits"] == out["b_final"]["nbits"] > 4000
@@ -65,11 +71,11 @@ def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_epochs,bits,qber", [(4, 4001, 0.02), (4, 15001, 0.02), (2, 9000, 0.03)])
 def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
-    """ECD2_LDPC=1: Bob (QBER follower) picks ALG_LDPC_CONTINUE_ROLES; one parity packet + one verdict instead of
+    """`-L 1` (ecd2's new option): Bob (QBER follower) picks ALG_LDPC_CONTINUE_ROLES; one parity packet + one verdict instead of
     ~55 cascade packets each way; both daemons write identical final keys."""
     binary = need("ecd2_ldpc")
     a, b = epochs(2, n_epochs, bits, qber)
-    out = run_loopback(binary, tmp_path, a, b, env_extra={"ECD2_LDPC": "1"})
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1"])
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0, out["b_log"][-2500:]
     assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
@@ -149,7 +155,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
     binary = need("ecd2_ldpc")
     a, b = epochs(7, 4, 6001, 0.02)
     clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"})
-    out = run_loopback(binary, tmp_path / "fault", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_LDPC_FAULT": "600"})
+    out = run_loopback(binary, tmp_path / "fault", a, b, extra_args=["-L", "1,x600"])
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     assert "no verified codeword" in out["b_log"]
     assert "falling back to cascade as EC follower" in out["b_log"] and "falling back to cascade as EC initiator" in out["a_log"]
@@ -160,14 +166,14 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
     # correctedErrors) exceeds M + 32 by cascade's own parities.  (Key LENGTHS of two runs cannot be compared: the QBER sample
     # is drawn from /dev/urandom, and with it the estimated error and the rate choice.)
     import re
-    M = int(re.search(r"sent parity, \d+ key bits, rate index \d+, K \d+, M (\d+)", out["a_log"]).group(1))
+    disclosed = int(re.search(r"sent parity in \d+ packet\(s\), \d+ key bits, rate index \d+, K \d+, M \d+, \d+ punctured, (\d+) bits disclosed", out["a_log"]).group(1))
     for log in (out["a_log"], out["b_log"]):
         corr = int(re.findall(r"corrected errors: (\d+)", log)[-1])
         leak = int(re.findall(r"leakageBits: (-?\d+)", log)[-1])
-        assert leak + corr > M + 32 + 100, (leak, corr, M)
+        assert leak + corr > disclosed + 100, (leak, corr, disclosed)
     assert clean["a_final"] is not None and clean["a_final"]["nbits"] > 0
     # dropping instead of falling back is still available
-    drop = run_loopback(binary, tmp_path / "drop", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_LDPC_FAULT": "600", "ECD2_LDPC_FALLBACK": "0"}, timeout=8)
+    drop = run_loopback(binary, tmp_path / "drop", a, b, extra_args=["-L", "1,x600,f0"], timeout=12)
     assert drop["a_final"] is None and drop["b_final"] is None
 
 
@@ -186,10 +192,10 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
     assert all((sizes[i] + sizes[i + 1]) % 32 for i in range(0, 16, 2))
     a = [rng.integers(0, 2, n).astype(np.uint8) for n in sizes]
     b = [x ^ (rng.random(x.size) < 0.03) for x in a]
-    env = {"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"}
-    one = run_loopback(binary, tmp_path / "one", a, b, env_extra=env, blocks=[2] * 8, timeout=90)
-    env_b = dict(env, ECD2_LDPC_BATCH="4", ECD2_LDPC_BATCH_WAIT_MS="1500")
-    bat = run_loopback(binary, tmp_path / "batch", a, b, env_extra=env_b, blocks=[2] * 8, timeout=90)
+    one = run_loopback(binary, tmp_path / "one", a, b, extra_args=["-L", "1,g"], blocks=[2] * 8, timeout=90)
+    bat = run_loopback(binary, tmp_path / "batch", a, b, extra_args=["-L", "1,g,b4,w1500"], blocks=[2] * 8, timeout=90)
+    # the mother codes were all built in ldpc_init: eight blocks of different length later, still the same 32 entries
+    assert "ldpc: engine ready" in bat["b_log"]
     for name, o in (("one", one), ("batch", bat)):
         missing = [hex(st) for st, (x, y) in o["finals"].items() if x is None or y is None]
         if missing:      # keep the daemons' logs where gpurun brings them back
@@ -208,3 +214,41 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
     batches = [int(x) for x in re.findall(r"decoded a batch of (\d+) blocks in one call", bat["b_log"])]
     assert sum(batches) == 8 and max(batches) >= 2, batches
     assert "decoded a batch" not in one["b_log"]
+
+
+@pytest.mark.gpu
+def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
+    """SURVEY.md 8f #4 second half / VERDICT r1 #4a, #8: two 60 001-bit epochs are loaded as ONE block of 120 002 bits (the LDPC build
+    raises MAX_BITS_PER_PROCESSBLOCK, processblock_mgmt.c:94-95; cascade with its unsigned short indices could not take it), at
+    QBER 6 % the rate-0.5 plan discloses > 50 000 parity bits; `-L p3000` makes every parity packet at most 3 000 bytes so the
+    payload travels in several fragments, which Bob reassembles before decoding.  Identical final keys on both sides."""
+    binary = need("ecd2_ldpc")
+    a, b = epochs(11, 2, 60001, 0.06)
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1,g,p3000"], timeout=150)
+    assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
+    import re
+    m = re.search(r"sent parity in (\d+) packet\(s\), (\d+) key bits", out["a_log"])
+    assert m and int(m.group(1)) >= 3 and int(m.group(2)) > 100000, out["a_log"][-2000:]
+    assert "decoded" in out["b_log"]
+    assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 10000
+    assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
+
+
+@pytest.mark.gpu
+def test_sample_without_errors_and_repeated_parity_packets(tmp_path):
+    """(1) identical keys -> the QBER sample has no error, localError = 0 (qber_estim.c:26); the plan clamps it instead
+    of refusing, the block reconciles (nothing to correct) and yields a key.  (2) a parity packet that arrives twice (`-L d1`
+    makes Alice send every parity packet twice) must not queue the block twice: with the batched ingest the second copy used to
+    decode a block that privacy amplification had already freed."""
+    binary = need("ecd2_ldpc")
+    rng = np.random.default_rng(23)
+    a = [rng.integers(0, 2, 5001).astype(np.uint8) for _ in range(4)]
+    out = run_loopback(binary, tmp_path / "clean", a, [x.copy() for x in a], extra_args=["-L", "1"], timeout=90)
+    assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
+    assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 10000 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
+    assert "0 errors corrected" in out["b_log"]
+    a2, b2 = epochs(29, 4, 5003, 0.02)
+    dup = run_loopback(binary, tmp_path / "dup", a2, b2, extra_args=["-L", "1,b2,w200"], extra_args_a=["-L", "1,b2,w200,d1"], timeout=90)
+    assert dup["a_final"] is not None and dup["b_final"] is not None, dup["a_log"][-2000:] + "\n----\n" + dup["b_log"][-2000:]
+    assert (dup["a_final"]["words"] == dup["b_final"]["words"]).all()
+    assert dup["b_log"].count("decoded 1") + dup["b_log"].count(": decoded ") >= 1 and "Segmentation" not in dup["b_log"]
