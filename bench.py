@@ -102,7 +102,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 4096 = BASELINE config 2 on one GPU; 32768 = config 4's shard when WORLD_SIZE > 1)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (multi-rate stream through the reconciliation sessions)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (N = 10^6 horizontal-layered)")
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--k", type=int, default=52429)
     ap.add_argument("--qber", type=float, default=0.02)
@@ -150,7 +152,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    F = args.frames
+    # BASELINE configs[1]: 4 096 frames on one GPU; configs[3]: 262 144 frames over 8 GPUs = 32 768 per GPU, the shard every rank of an
+    # N > 1 run decodes (weak scaling: the per-GPU batch stays config 4's whatever N is)
+    F = args.frames if args.frames > 0 else (4096 if world == 1 else 32768)
     total_frames = F * world
     lo, hi = shard.frame_range(total_frames, world, rank)
     code = q.Code.ira(args.n, args.k, 0.125, 11, 3, 7)
@@ -173,13 +177,14 @@ def main():
         return d
 
     out = torch.empty((F, (N + 31) // 32), dtype=torch.int32, device=device)
+    gbuf = shard.gather_buffer(out, total_frames, dst=0) if world > 1 else None      # rank 0's receive buffer, allocated once
 
     def step(dec):
         dec.load_bits(rx, mag, cls)
         dec.run()
         dec.fetch_packed(out)
         if world > 1:
-            shard.gather_blocks(out, total_frames, dst=0)
+            shard.gather_blocks(out, total_frames, dst=0, out=gbuf)      # the one collective of the job: RCCL gather of decoded blocks
 
     def timed(dec, steps, warmup):
         for _ in range(warmup):
@@ -283,6 +288,111 @@ def main():
     fp16 = variant("f16") if not args.no_fp16 else None
     int8 = variant("i8") if (not args.no_int8 and args.rule in ("MS", "OMS", "NMS")) else None
 
+    # ---- BASELINE config 5: N = 10^6 irregular LDPC, horizontal-layered schedule, per-sweep syndrome early termination ----------
+    def config5():
+        n5, k5, f5 = 1000000, 800000, 64
+        code5 = q.Code.ira(n5, k5, 0.125, 11, 3, 7)
+        enc5 = q.Encoder(code5, "IRA", device=local_rank)
+        cw5, rx5 = make_frames(q, torch, code5, enc5, f5, args.qber, 5000, device)
+        mag5 = torch.full((f5,), q.bsc_llr(args.qber), dtype=torch.float32, device=device)
+        cls5 = torch.zeros(n5, dtype=torch.uint8, device=device)
+        cls5[k5:] = q.VN_PINNED
+        out5 = torch.empty((f5, (n5 + 31) // 32), dtype=torch.int32, device=device)
+        res = {}
+        for name, synd in (("fixed", False), ("early_exit", True)):
+            d5 = q.Decoder(code5, k5, args.n_ite, rule="NMS", rule_param=args.alpha, enable_syndrome=synd, n_frames=f5, device=local_rank, schedule="hlayered")
+            d5.set_stream(torch.cuda.current_stream(device))
+
+            def step5():
+                d5.load_bits(rx5, mag5, cls5)
+                d5.run()
+                d5.fetch_packed(out5)
+            d5.profile(True)
+            step5()
+            d5.profile_clear()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            n5steps = 3
+            for _ in range(n5steps):
+                step5()
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - t
+            ks = {s_["name"]: s_ for s_ in d5.profile_read()}
+            d5.profile(False)
+            it5, ok5 = d5.fetch_status()
+            good5 = float((((out5 == cw5).all(dim=1)) & (ok5 == 1)).sum())
+            lay = ks["layer_update"]
+            res[name] = dict(value=good5 * k5 * n5steps / dt5 / 1e6, unit="Mbit/s", fer=1.0 - good5 / f5, avg_sweeps=float(it5.float().mean()),
+                             sweeps_launched=d5.last_run_iterations, ms_per_step=dt5 / n5steps * 1e3,
+                             roofline=dict(bound="hbm", kernel="qk_cn_layer (one sweep = all colour layers)", peak=HBM_PEAK_GBS, unit="GB/s",
+                                           alg_bytes_per_sweep=lay["alg_bytes"] / lay["launches"], moved_bytes_per_sweep=lay["moved_bytes"] / lay["launches"],
+                                           avg_sweep_ms=lay["total_ms"] / lay["launches"], sweeps=lay["launches"],
+                                           achieved=lay["alg_bytes"] / (lay["total_ms"] * 1e-3) / 1e9, frac=lay["alg_bytes"] / (lay["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS))
+            del d5
+            torch.cuda.empty_cache()
+        res["workload"] = "N=%d K=%d IRA LDPC (E=%d, %d colour layers), horizontal-layered NMS(%.2f), <= %d sweeps, syndrome test every sweep, QBER %.1f %%, %d frames" % (
+            n5, k5, code5.E, code5.n_layers, args.alpha, args.n_ite, args.qber * 100, f5)
+        return res
+
+    # ---- BASELINE config 3: multi-rate H set {0.5, 0.7, 0.8, 0.9} chosen per epoch from the estimated QBER, a stream of epochs through
+    #      the reconciliation sessions (what the ecd2 handlers call), HOST buffers in and out ----------------------------------------
+    def config3():
+        epochs_n, key_bits, batch = 512, 52429, 64
+        rng = np.random.default_rng(42)
+        qbers = rng.uniform(0.005, 0.06, epochs_n).astype(np.float32)
+        alice = rng.integers(0, 2, (epochs_n, key_bits)).astype(np.uint8)
+        bob = alice ^ (rng.random((epochs_n, key_bits)) < qbers[:, None])
+        aw, bw = q.pack_bits(alice), q.pack_bits(bob)
+        ra, rb = q.Recon(device=local_rank, max_blocks=batch), q.Recon(device=local_rank, max_blocks=batch)
+        keys = [aw[i] for i in range(epochs_n)]
+        ra.encode_blocks(keys, [key_bits] * epochs_n, qbers)                  # builds the codes of the table (warm-up)
+        t = time.perf_counter()
+        msgs, pars = ra.encode_blocks(keys, [key_bits] * epochs_n, qbers)
+        t_enc = time.perf_counter() - t
+        groups = {}
+        for i, m in enumerate(msgs):
+            groups.setdefault((m.rate_index, m.code_k, m.code_m), []).append(i)
+        for idx in groups.values():                                           # Bob's decoders of the table (warm-up)
+            rb.decode_batch(bw[idx[:1]], key_bits, qbers[idx[:1]], [msgs[idx[0]]], [pars[idx[0]]])
+        ok = np.zeros(epochs_n, bool)
+        iters = np.zeros(epochs_n, int)
+
+        def stream():
+            for idx in groups.values():
+                for lo_ in range(0, len(idx), batch):
+                    j = idx[lo_:lo_ + batch]
+                    st, fixed, co, it_ = rb.decode_batch(bw[j], key_bits, qbers[j], [msgs[k_] for k_ in j], [pars[k_] for k_ in j])
+                    ok[j] = (st == 0) & (fixed == aw[j]).all(axis=1)
+                    iters[j] = it_
+        t = time.perf_counter()
+        stream()                                                              # the timed pass: no profiling events on the stream
+        dt3 = time.perf_counter() - t
+        rb.profile(True)
+        stream()                                                              # the same stream again for the per-kernel split
+        ks = {s_["name"]: s_ for s_ in rb.profile_read()}
+        rb.profile(False)
+        leak = sum(q.Recon.leaked_bits(msgs[i]) for i in range(epochs_n) if ok[i])
+        kern_ms = sum(s_["total_ms"] for s_ in ks.values())
+        hot = [ks[k_] for k_ in ("cn_update", "vn_update") if k_ in ks]
+        return dict(value=float(ok.sum()) * key_bits / dt3 / 1e6, unit="Mbit/s of sifted key, host buffers in and out (PCIe, CRC and packing included)",
+                    fer=float(1.0 - ok.mean()), leaked_fraction=float(leak) / max(1.0, float(ok.sum()) * key_bits),
+                    configured_efficiency=1.4, avg_iterations=float(iters.mean()), ms_total=dt3 * 1e3, alice_encode_ms=t_enc * 1e3,
+                    epochs_per_rate={("%.1f" % ra.rates[k_[0]]): len(v) for k_, v in sorted(groups.items())},
+                    roofline=dict(bound="hbm", kernel="qk_cn_flood + qk_vn_flood of the session decoders (SPA, early exit, batches of <= %d blocks)" % batch,
+                                  peak=HBM_PEAK_GBS, unit="GB/s", alg_bytes=sum(s_["alg_bytes"] for s_ in hot), moved_bytes=sum(s_["moved_bytes"] for s_ in hot),
+                                  kernel_ms=sum(s_["total_ms"] for s_ in hot), all_kernels_ms=kern_ms,
+                                  achieved=sum(s_["alg_bytes"] for s_ in hot) / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9,
+                                  frac=sum(s_["alg_bytes"] for s_ in hot) / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                    workload="%d epochs x %d bits, QBER ~ U[0.5 %%, 6 %%] (seed 42), rate per epoch from {0.5, 0.7, 0.8, 0.9} (f = 1.4, kept 0.035 (65536/K)^0.4 "
+                             "from capacity), mother code K = 57344 shortened + punctured per epoch, flooding SPA, blocks of one code batched" % (epochs_n, key_bits))
+
+    cfg3 = cfg5 = None
+    if rank == 0 and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32" and (N, K) == (65536, 52429):
+        if not args.no_config5:
+            cfg5 = config5()
+        if not args.no_config3:
+            cfg3 = config3()
+
     # ---- CPU baseline (rank 0, N = 1 only) -------------------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -338,8 +448,9 @@ def main():
             "frames_per_step": int(n_all),
             "config": {
                 "workload": "rate-%.1f N=%d IRA LDPC (K=%d, M=%d, E=%d), flooding %s(%.2f), %d iterations fixed, QBER %.1f %%, "
-                            "%d frames per GPU, packed bits resident in HBM" % (K / N, N, K, code.M, code.E, args.rule, args.alpha, args.n_ite,
-                                                                               args.qber * 100, F),
+                            "%d frames per GPU (%s), packed bits resident in HBM" % (K / N, N, K, code.M, code.E, args.rule, args.alpha, args.n_ite,
+                                                                                     args.qber * 100, F, "BASELINE configs[1]" if (world == 1 and F == 4096) else
+                                                                                     ("BASELINE configs[3]: 262144 / 8 frames per GPU" if F == 32768 else "custom batch")),
                 "frames_per_gpu": F, "qber": args.qber, "n_ite": args.n_ite, "rule": args.rule, "alpha": args.alpha,
                 "parallelism": "frame-sharded x%d, RCCL gather of decoded blocks only" % world,
             },
@@ -361,6 +472,8 @@ def main():
             "early_exit": early,
             "fp16_messages": fp16,
             "int8_messages": int8,
+            "config3_multirate_stream": cfg3,
+            "config5_layered_1e6": cfg5,
             "reference_context": {"aff3ct_spa_1thread_debug_Mbit_s": 0.241, "cascade_daemon_Mbit_s": 0.3},
         }
         print(json.dumps(line), flush=True)

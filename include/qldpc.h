@@ -340,6 +340,9 @@ int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon
 int qldpc_recon_parity_words(const qldpc_recon_msg *msg);    /* words of disclosed parity a message carries: ceil((code_m - n_punct)/32) */
 int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg);     /* code_m - n_punct + 32 (CRC)                                             */
 long qldpc_recon_entries_created(const qldpc_recon *r);      /* (code, encoder, decoder) sets built so far: constant after a preload   */
+/* qldpc_profile_enable / _read of Bob's decoders, summed over the session's codes by kernel kind */
+int qldpc_recon_profile_enable(qldpc_recon *r, int on);
+int qldpc_recon_profile_read(qldpc_recon *r, qldpc_kernel_stat *out, int cap);
 /* Alice: the disclosed parity bits (qldpc_recon_parity_words(msg_out) words, MSB-first, in position order) + message header. */
 int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber,
                        qldpc_recon_msg *msg_out, uint32_t *parity_words, int parity_cap_words);

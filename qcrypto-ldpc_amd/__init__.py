@@ -530,6 +530,8 @@ _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
 _sig("qldpc_recon_parity_words", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_leaked_bits", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_entries_created", C.c_long, [_vp])
+_sig("qldpc_recon_profile_enable", C.c_int, [_vp, C.c_int])
+_sig("qldpc_recon_profile_read", C.c_int, [_vp, C.POINTER(KernelStat), C.c_int])
 
 
 _sig("qldpc_privamp", C.c_int, [C.c_int, _up, C.c_int, C.c_uint32, C.c_int, _up])
@@ -596,6 +598,16 @@ class Recon:
     @property
     def entries_created(self):
         return int(_L.qldpc_recon_entries_created(self._h))
+
+    def profile(self, on=True):
+        _chk(_L.qldpc_recon_profile_enable(self._h, int(on)), "Recon.profile")
+
+    def profile_read(self):
+        arr = (KernelStat * 16)()
+        n = _L.qldpc_recon_profile_read(self._h, arr, 16)
+        _chk(n, "Recon.profile_read")
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                     alg_bytes=float(arr[i].alg_bytes), moved_bytes=float(arr[i].moved_bytes)) for i in range(n)]
 
     def encode(self, key_words, key_bits, qber):
         """Alice: -> (msg, parity_words)."""

@@ -244,6 +244,31 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
 
 extern "C" long qldpc_recon_entries_created(const qldpc_recon *r) { return r ? r->created : -1; }
 
+/* per-kernel profile of Bob's decoders (qldpc_profile_*), summed over the codes of the session */
+extern "C" int qldpc_recon_profile_enable(qldpc_recon *r, int on)
+{
+    if (!r) return QLDPC_EINVAL;
+    for (auto &e : r->cache) { qldpc_profile_enable(e.dec, on); if (on) qldpc_profile_clear(e.dec); }
+    return QLDPC_OK;
+}
+extern "C" int qldpc_recon_profile_read(qldpc_recon *r, qldpc_kernel_stat *out, int cap)
+{
+    if (!r || (!out && cap > 0)) return QLDPC_EINVAL;
+    int n = 0;
+    for (auto &e : r->cache) {
+        qldpc_kernel_stat st[16];
+        const int m = qldpc_profile_read(e.dec, st, 16);
+        if (m < 0) return m;
+        for (int i = 0; i < m; i++) {
+            int k = 0;
+            while (k < n && strcmp(out[k].name, st[i].name)) k++;
+            if (k == n) { if (n >= cap) continue; out[n] = st[i]; n++; continue; }
+            out[k].launches += st[i].launches; out[k].total_ms += st[i].total_ms; out[k].alg_bytes += st[i].alg_bytes; out[k].moved_bytes += st[i].moved_bytes;
+        }
+    }
+    return n;
+}
+
 /*
  * Rate choice, code dimensions and puncturing of a block (BS/src/main.cpp:29-34,235-311).  The QBER estimate is clamped to
  * [0.001, 0.25] first: the daemon's localError is exactly 0 when the test sample held no error (qber_estim.c:26).

@@ -15,11 +15,23 @@ def frame_range(total_frames, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_blocks(local, total_frames, dst=0, group=None):
+def gather_buffer(local, total_frames, dst=0, group=None):
+    """Receive buffer for gather_blocks on `dst`: [world, cap, ...] (cap = the largest shard), allocated ONCE by the caller so that
+    a timed step holds the collective and nothing else.  None on the other ranks."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or dist.get_rank(group) != dst:
+        return None
+    world = dist.get_world_size(group)
+    cap = max(hi - lo for lo, hi in (frame_range(total_frames, world, r) for r in range(world)))
+    dev = local.device if dist.get_backend(group) == "nccl" or not local.is_cuda else torch.device("cpu")
+    return torch.empty((world, cap) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+
+
+def gather_blocks(local, total_frames, dst=0, group=None, out=None):
     """Gather per-frame rows (dim 0 = this rank's frame_range) to `dst` in global frame order.
 
-    Returns the [total_frames, ...] tensor on dst and None elsewhere.  Shards may be ragged, so every
-    rank pads to the largest shard and dst trims; one all_gather-free `dist.gather` is the whole exchange.
+    Returns the [total_frames, ...] tensor on dst and None elsewhere: ONE `dist.gather` is the whole exchange (RCCL over xGMI on GPUs).
+    With `out` = gather_buffer(...) the rows land in that preallocated buffer and, when every rank holds the same number of
+    frames, the result is a view of it (no allocation, no copy); ragged shards are padded to the largest one and trimmed on dst.
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
@@ -34,8 +46,15 @@ def gather_blocks(local, total_frames, dst=0, group=None):
     local = local.contiguous()
     if local.is_cuda and dist.get_backend(group) != "nccl":
         local = local.cpu()            # gloo rehearsal: stage through host memory
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        assert tuple(out.shape) == (world,) + tuple(local.shape) and out.dtype == local.dtype and out.device == local.device
+        bufs = [out[r] for r in range(world)]
     dist.gather(local, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([b[: h - l] for b, (l, h) in zip(bufs, sizes)], 0)
+    if all(h - l == cap for l, h in sizes):
+        return out.view((world * cap,) + tuple(local.shape[1:]))
+    return torch.cat([out[r, : h - l] for r, (l, h) in enumerate(sizes)], 0)

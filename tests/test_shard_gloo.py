@@ -23,11 +23,18 @@ def _worker(rank, world, port, total, width, q_out):
     # a "decoded block" that is a pure function of the global frame id
     local = (torch.arange(lo, hi, dtype=torch.int32)[:, None] * 7 + torch.arange(width, dtype=torch.int32)[None, :])
     out = sh.gather_blocks(local, total, dst=0)
+    # the bench's form: a receive buffer allocated once, the gather lands in it (a view of it when the shards are equal)
+    buf = sh.gather_buffer(local, total, dst=0)
+    out2 = sh.gather_blocks(local, total, dst=0, out=buf)
+    out3 = sh.gather_blocks(local + 1, total, dst=0, out=buf)
     if rank == 0:
         exp = torch.arange(total, dtype=torch.int32)[:, None] * 7 + torch.arange(width, dtype=torch.int32)[None, :]
-        q_out.put(bool((out == exp).all()) and out.shape == exp.shape)
+        ok = bool((out == exp).all()) and out.shape == exp.shape and bool((out3 == exp + 1).all()) and out3.shape == exp.shape
+        if total % world == 0:
+            ok = ok and out3.data_ptr() == buf.data_ptr()          # no allocation, no copy
+        q_out.put(ok and out2.shape == exp.shape)
     else:
-        assert out is None
+        assert out is None and buf is None and out2 is None
     dist.barrier()
     dist.destroy_process_group()
 
