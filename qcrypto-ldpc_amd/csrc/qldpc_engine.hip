@@ -638,7 +638,7 @@ static int run_layered(qldpc_decoder *d)
     HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));                                                                                       /* messages = 0   */
     auto ballots = [&]() {
         if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr, d->N, d->d_done);
-        else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
+        else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)std::max(1, std::min((d->N + 32 * QK_WAVES - 1) / (32 * QK_WAVES), 8192 / std::max(1, d->G))), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
     };
     int ite = 0;
     for (; ite < n_ite; ite++) {

@@ -739,17 +739,32 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
     const int g = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int v = blockIdx.x * QK_WAVES + wave; v < N; v += gridDim.x * QK_WAVES) {
-        float p[V];
-        qk_load<V>(p, post + ((size_t)g * N + v) * FG + lane * V);
+    /* one wavefront takes 32 consecutive VNs per trip; their 32 sgn + 32 hard ballot words (of frame slot j) leave in ONE store
+     * instruction -- lane 2k carries the sgn word of VN k, lane 2k + 1 its hard word (lane-0 stores were one instruction per word) */
+    for (int v0 = (blockIdx.x * QK_WAVES + wave) * 32; v0 < N; v0 += gridDim.x * QK_WAVES * 32) {
+        u64 mine[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) {
-            u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
-            u64 h = __ballot(!(p[j] >= 0.0f));
-            const size_t bi = ((size_t)g * N + v) * V + j;
-            const u64 dm = done[(size_t)g * V + j];      /* converged frames keep the ballots they converged with */
-            if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
-            if (lane == 0) { sgn[bi] = s; hard[bi] = h; }
+        for (int j = 0; j < V; j++) mine[j] = 0;
+        for (int k = 0; k < 32; k++) {
+            const int v = v0 + k;
+            if (v >= N) break;      /* wave-uniform */
+            float p[V];
+            qk_load<V>(p, post + ((size_t)g * N + v) * FG + lane * V);
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
+                u64 h = __ballot(!(p[j] >= 0.0f));
+                const size_t bi = ((size_t)g * N + v) * V + j;
+                const u64 dm = done[(size_t)g * V + j];      /* converged frames keep the ballots they converged with */
+                if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
+                if (lane == 2 * k) mine[j] = s;
+                if (lane == 2 * k + 1) mine[j] = h;
+            }
+        }
+        const int v = v0 + (lane >> 1);
+        if (v < N) {
+#pragma unroll
+            for (int j = 0; j < V; j++) ((lane & 1) ? hard : sgn)[((size_t)g * N + v) * V + j] = mine[j];
         }
     }
 }
@@ -1042,14 +1057,22 @@ __global__ __launch_bounds__(QK_THREADS) void qk_load_syndrome(const uint32_t *_
         uint32_t word[V];
 #pragma unroll
         for (int j = 0; j < V; j++) { const int f = g * FG + lane * V + j; word[j] = f < n_frames ? bits[(size_t)f * Wm + w] : 0u; }
+        /* the 32 ballot words of this input word leave in one store per frame slot: lane b carries the word of item 32 w + b */
+        u64 mine[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) mine[j] = 0;
         for (int b = 0; b < 32; b++) {
-            const int c = w * 32 + b;
-            if (c >= M) break;
+            if (w * 32 + b >= M) break;
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 const u64 m = __ballot((word[j] >> (31 - b)) & 1u);
-                if (lane == 0) synd[((size_t)g * M + c) * V + j] = m;
+                if (lane == b) mine[j] = m;
             }
+        }
+        const int c = w * 32 + lane;
+        if (lane < 32 && c < M) {
+#pragma unroll
+            for (int j = 0; j < V; j++) synd[((size_t)g * M + c) * V + j] = mine[j];
         }
     }
 }

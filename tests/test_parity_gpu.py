@@ -476,3 +476,37 @@ def test_per_frame_erasures(q, O, torch, variant):
     it, ok = dec.fetch_status()
     assert (hard == ref["hard"]).all() and (it.cpu().numpy() == ref["iters"]).all() and (ok.cpu().numpy() == ref["synd_ok"]).all()
     assert (ref["synd_ok"] == 1).mean() > 0.5
+
+
+@pytest.mark.parametrize("engine", ["frames", "edges"])
+def test_spa_tolerance_at_scale(q, O, torch, peg, engine):
+    """SURVEY.md section 8c, the tolerance of the float-LLR SPA variant, in the driver's suite: over >= 10^4 frames inside the waterfall
+    >= 99.9 % of the frame verdicts (reconciled / not) are the oracle's and the GPU's FER lies inside the binomial 95 % interval around
+    the oracle's (device exp / log / rcp differ from glibc's tanh / atanh in the last ulp; the edge engine also multiplies in tree
+    order).  tests/spa_verdicts.py is the same check on the full-size config-2 code (10 240 frames, QBER 3.0 %: all verdicts identical)."""
+    code, og = peg
+    F, N = 10240, 1008
+    rng = np.random.default_rng(31)
+    enc = q.Encoder(code, "IDENTITY")
+    cw = enc.encode(rng.integers(0, 2, (F, enc.K)))
+    y = cw ^ (rng.random((F, N)) < 0.07)
+    llr = np.where(y == 1, -2.5866892, 2.5866892).astype(np.float32)   # ln((1 - p) / p) at p = 0.07: FER 0.15, inside the waterfall
+    ref = O.decode(og, llr, "SPA", 0.0, 30, "flooding", True, 1, n_threads=min(16, os.cpu_count() or 8))
+    o_good = (ref["hard"] == cw).all(axis=1) & (ref["synd_ok"] == 1)
+    hard = np.empty((F, N), np.uint8)
+    okg = np.empty(F, np.int32)
+    B = 2048
+    dec = q.Decoder(code, N, 30, rule="SPA", n_frames=B, engine=engine)
+    for lo in range(0, F, B):
+        dec.load_llr(torch.from_numpy(llr[lo:lo + B]).cuda())
+        dec.run()
+        hard[lo:lo + B] = q.unpack_bits(dec.fetch_packed().cpu().numpy().view(np.uint32), N)
+        okg[lo:lo + B] = dec.fetch_status()[1].cpu().numpy()
+    g_good = (hard == cw).all(axis=1) & (okg == 1)
+    p = 1.0 - o_good.mean()
+    assert 0.02 < p < 0.6, p                                             # inside the waterfall: both outcomes are plentiful
+    assert (g_good == o_good).mean() >= 0.999, (g_good == o_good).mean()
+    ci = 1.96 * np.sqrt(p * (1 - p) / F)
+    assert abs((1.0 - g_good.mean()) - p) <= ci, (1.0 - g_good.mean(), p, ci)
+    same = (hard == ref["hard"]).all(axis=1)
+    assert same[o_good].mean() >= 0.999                                  # and on frames the oracle reconciles it is the same word
