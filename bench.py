@@ -416,17 +416,26 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
     # committed rocprofv3 --pmc summary of the SAME command (profiles/), used only when the workload matches.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, vn_traffic = None, None, None
     if rank == 0:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")))
+            pmc_path = os.path.join("profiles", "r02_fixed50_pmc_hbm_traffic.json")
+            pmc = json.load(open(os.path.join(ROOT, pmc_path)))
             w = pmc["workload"]
             fpl = args.frames_per_lane or 1
-            if (w["frames"], w["frames_per_lane"], w["N"], w["E"]) == (F, fpl, N, code.E):
-                traffic = pmc["kernels"]["qk_cn_flood<%d, 20, 0, float, false>" % fpl]["hbm_bytes_corrected"]
-                traffic_src = "profiles/r01_d_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)"
-        except Exception:
-            pass
+            if (w["frames"], w["frames_per_lane"], w["N"], w["E"]) == (F, fpl, N, code.E) and args.msg_dtype == "f32" and args.rule == "NMS":
+                # the steady-state kernels of the fixed-50 leg, whatever further template arguments they have grown
+                cnk = [k_ for k_ in pmc["kernels"] if k_.startswith("qk_cn_flood<%d, 20, 0, float, false" % fpl)]
+                vnk = [k_ for k_ in pmc["kernels"] if k_.startswith("qk_vn_flood<%d," % fpl) and ", 1, float, true>" in k_]
+                if len(cnk) == 1:
+                    traffic = pmc["kernels"][cnk[0]]["hbm_bytes_corrected"]
+                    traffic_src = pmc_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of: " + pmc["source"].split(" -- ", 1)[-1] + "; gfx950-corrected)"
+                if vnk:
+                    vn_traffic = sum(pmc["kernels"][k_]["hbm_bytes_corrected"] for k_ in vnk)      # one VN pass = its degree buckets' launches
+        except Exception as ex:      # noqa: BLE001
+            log("no PMC traffic file for this workload: %s" % ex)
+        if traffic is None and (F, N, args.msg_dtype, args.rule, args.schedule) == (4096, 65536, "f32", "NMS", "flooding"):
+            log("warning: roofline.traffic is null although the workload is the profiled one -- kernel names changed? re-run tools/pmc_summary.py")
 
     if rank == 0:
         line = {
@@ -462,7 +471,7 @@ def main():
                 # fetches with coded LLRs (N / 8 B of received-bit ballots per frame)
                 "vn_update": {"achieved": vn_achieved, "frac": vn_achieved / HBM_PEAK_GBS, "moved": vn_moved, "moved_frac": vn_moved / HBM_PEAK_GBS,
                               "alg_bytes_per_pass": vn["alg_bytes"] / vn["launches"], "moved_bytes_per_pass": vn["moved_bytes"] / vn["launches"],
-                              "avg_pass_ms": vn["total_ms"] / vn["launches"], "passes": vn["launches"]},
+                              "avg_pass_ms": vn["total_ms"] / vn["launches"], "passes": vn["launches"], "traffic": vn_traffic},
                 "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                "moved_bytes": step_moved, "moved": step_moved / (dt / args.steps) / 1e9,

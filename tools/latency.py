@@ -60,3 +60,23 @@ t0 = time.perf_counter()
 for _ in range(10):
     r.encode(aw, 60000, 0.02)
 print("recon_encode: %.1f us" % ((time.perf_counter() - t0) / 10 * 1e6))
+
+# ---- first-block and cache-miss latency of the sessions: a code per block size (round 1) vs preloaded mother codes ----------
+sizes = [60000, 41935, 33000, 52429, 20011, 64999, 60000]
+for label, kw in (("per-size codes, built on first use (mother_step=0)", dict(mother_step=0)),
+                  ("mother codes, built on first use", dict()),
+                  ("mother codes preloaded at create (ldpc_init)", dict(preload=True))):
+    t0 = time.perf_counter()
+    ra, rb = q.Recon(max_blocks=1, **kw), q.Recon(max_blocks=1, **kw)
+    t_create = time.perf_counter() - t0
+    lat = []
+    for kb in sizes:
+        x = rng.integers(0, 2, kb).astype(np.uint8)
+        y = x ^ (rng.random(kb) < 0.02)
+        m, p = ra.encode(q.pack_bits(x), kb, 0.02)
+        before = rb.entries_created
+        t0 = time.perf_counter()
+        okb, *_ = rb.decode(q.pack_bits(y), kb, 0.02, m, p)
+        lat.append(((time.perf_counter() - t0) * 1e3, rb.entries_created - before, bool(okb)))
+    print("%-52s create %7.1f ms | decode latency per block [ms (codes built)]: %s" % (
+        label, t_create * 1e3, "  ".join("%.2f (%d)%s" % (l, n, "" if o else "!") for l, n, o in lat)), flush=True)
