@@ -100,7 +100,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
-    (void)hipFree(d->e_c2v1); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
+    (void)hipFree(d->e_c2v1); (void)hipFree(d->e_ctl); (void)hipFree(d->e_sgn); (void)hipFree(d->e_hard); (void)hipFree(d->e_unsat); (void)hipFree(d->e_done_at);
     if (d->h_done) (void)hipHostFree(d->h_done);
     for (auto &g : d->e_graphs) if (g) (void)hipGraphExecDestroy(g);
     if (d->cap_stream) (void)hipStreamDestroy(d->cap_stream);
@@ -223,6 +223,12 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
          * the host), so graphs stay opt-in */
         d->use_graphs = 0; d->graph_frames = -1;
         if (const char *e = getenv("QLDPC_GRAPH")) d->use_graphs = atoi(e) ? 1 : 0;
+        /* QLDPC_EDGE_PERSIST=1: the whole decode of up to 8 blocks as ONE launch, one XCD per block (qe_xcd).  Off by default: measured
+         * 964 us per 65 536-VN block against 325 us with a launch per pass (a chunk of 64 checks is a chain of dependent L2 round trips,
+         * ~8 us, and one XCD has a fifth of the workgroup slots the chunks of a block would fill) */
+        d->persist = 0;
+        if (const char *e = getenv("QLDPC_EDGE_PERSIST")) d->persist = (atoi(e) && cfg->max_frames <= QE_PERSIST_MAX_FRAMES) ? 1 : 0;
+        if ((rc = dev_alloc(d, &d->e_ctl, QE_CTL_WORDS))) return rc;      /* claim / rank / barrier / fault words of qe_xcd */
         return QLDPC_OK;
     }
     if (cfg->schedule == QLDPC_SCHED_FLOODING) {
@@ -342,7 +348,12 @@ static int ensure_llr(qldpc_decoder *d)
 
 extern "C" int qldpc_decoder_set_stream(qldpc_decoder *d, void *s) { if (!d) return QLDPC_EINVAL; d->stream = (hipStream_t)s; return QLDPC_OK; }
 extern "C" size_t qldpc_decoder_device_bytes(const qldpc_decoder *d) { return d ? d->bytes : 0; }
-extern "C" int qldpc_last_run_iterations(const qldpc_decoder *d) { return d ? d->last_iters : QLDPC_EINVAL; }
+extern "C" int qldpc_last_run_iterations(const qldpc_decoder *dc)
+{
+    qldpc_decoder *d = const_cast<qldpc_decoder *>(dc);
+    if (!d) return QLDPC_EINVAL;
+    return d->last_iters;
+}
 
 /* early-exit bookkeeping of the last run (FRAMES engine): out[0] = lane-iterations executed (groups that ran an iteration x frames
  * per group, counted by the status pass), out[1] = compactions, out[2] = groups in the last generation, out[3] = frames per group.
@@ -802,9 +813,78 @@ static int edge_chunk_graph(qldpc_decoder *d, int chunk, int ite0, int ite1, hip
     return QLDPC_OK;
 }
 
+template <int S, int FAM>
+static int launch_persist(qldpc_decoder *d)
+{
+    const void *fn = (const void *)&qe_xcd<S, FAM>;
+    const size_t lds = std::max((size_t)(2 * QE_MAX_EDGES + 16) * sizeof(float), d->e_lds);
+    if (d->persist_blocks == 0) {
+        int per_cu = 0, cus = 0;
+        if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, QE_THREADS, lds));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device));
+        /* workgroups that can be resident on ONE XCD (an eighth of the CUs); the occupancy query is advisory (it can over-report by one
+         * workgroup per CU), so one per CU is given away and at most 4 are counted on */
+        const int reported = per_cu;
+        per_cu = std::min(4, per_cu - 1);
+        d->persist_blocks = per_cu * (cus / 8);
+        if (const char *e = getenv("QLDPC_EDGE_WGS")) d->persist_blocks = atoi(e);      /* workgroups per block (experiments) */
+        if (getenv("QLDPC_DEBUG")) fprintf(stderr, "libqldpc: one-launch edge decode: occupancy query %d workgroups per CU, %d CUs, %d workgroups per block, %zu B LDS\n", reported, cus, d->persist_blocks, lds);
+        if (d->persist_blocks < 1 || cus < 8) { d->persist = 0; return QLDPC_EUNSUPPORTED; }
+    }
+    const int nCN = (d->M + QE_CPB - 1) / QE_CPB, nVN = (d->N + QE_THREADS - 1) / QE_THREADS;
+    int nb = std::max(1, std::min(d->persist_blocks, std::max(nCN, nVN)));
+    qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    float *v2c = d->d_a, *c2v0 = d->d_b, *c2v1 = d->e_c2v1;
+    const float *llr = d->d_llr;
+    const int *cn_ptr = d->d_cn_ptr, *cn_tr = d->d_cn_tr, *cn_var = d->d_cn_var, *vn_ptr = d->d_vn_ptr;
+    uint32_t *sgn = d->e_sgn, *hard = d->e_hard;
+    int N = d->N, M = d->M, E = d->E, W = d->eW, F = d->n_frames, n_ite = d->cfg.n_ite, synd_on = d->cfg.enable_syndrome, depth = d->cfg.syndrome_depth, stride = d->e_stride;
+    int Wm = (d->M + 31) / 32;
+    int *unsat = d->e_unsat, *done_at = d->e_done_at, *ctl = d->e_ctl;
+    const uint32_t *synd = d->has_synd ? d->e_synd : nullptr;
+    static const int ctl_init[QE_CTL_WORDS] = {-1, -1, -1, -1, -1, -1, -1, -1};      /* the rest zero */
+    HIPCHK(hipMemcpyAsync(d->e_ctl, ctl_init, sizeof(ctl_init), hipMemcpyHostToDevice, d->stream));
+    /* twice the workgroups the 8 XCDs could use: the surplus (and the whole share of an XCD that got no block) exits at once */
+    const unsigned grid = (unsigned)(8 * nb * 2);
+    hipLaunchKernelGGL((qe_xcd<S, FAM>), dim3(grid), dim3(QE_THREADS), lds, d->stream, v2c, c2v0, c2v1, llr, cn_ptr, cn_tr, cn_var, vn_ptr, sgn, hard,
+                       N, M, E, W, F, nb, n_ite, synd_on, depth, unsat, stride, done_at, r, synd, Wm, ctl);
+    LAUNCHCHK();
+    /* the host needs the verdict now anyway (the launch-per-pass path polls as well): read the control words back; a decode that did
+     * not complete (a workgroup that never became resident: the grid drains on its bounded waits and says so) is repeated with a
+     * launch per pass by the caller, and the one-launch path is switched off for this decoder */
+    int ctl_h[QE_CTL_WORDS];
+    HIPCHK(hipMemcpyAsync(ctl_h, d->e_ctl, sizeof(ctl_h), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (ctl_h[QE_CTL_FAULT] || ctl_h[QE_CTL_NEXT] < F) {
+        fprintf(stderr, "libqldpc: one-launch edge decode did not complete (barrier time-out %d, %d of %d blocks claimed): falling back to a launch per pass\n",
+                ctl_h[QE_CTL_FAULT], ctl_h[QE_CTL_NEXT], F);
+        d->persist = 0;
+        return QLDPC_EUNSUPPORTED;
+    }
+    d->last_iters = ctl_h[QE_CTL_ITERS];
+    return QLDPC_OK;
+}
+
+static int run_edges_persist(qldpc_decoder *d)
+{
+    const bool spa = d->cfg.rule == QLDPC_RULE_SPA;
+    switch (d->eS) {
+    case 8: return spa ? launch_persist<8, QK_FAM_SPA>(d) : launch_persist<8, QK_FAM_MS>(d);
+    case 16: return spa ? launch_persist<16, QK_FAM_SPA>(d) : launch_persist<16, QK_FAM_MS>(d);
+    case 32: return spa ? launch_persist<32, QK_FAM_SPA>(d) : launch_persist<32, QK_FAM_MS>(d);
+    default: return spa ? launch_persist<64, QK_FAM_SPA>(d) : launch_persist<64, QK_FAM_MS>(d);
+    }
+}
+
 static int run_edges(qldpc_decoder *d)
 {
     int rc;
+    d->iters_pending = 0;
+    if (d->persist && !d->prof_on && d->n_frames <= QE_PERSIST_MAX_FRAMES) {
+        rc = run_edges_persist(d);
+        if (rc != QLDPC_EUNSUPPORTED) return rc;      /* not co-resident on this device: the launch-per-pass path below */
+    }
     const int n_ite = d->cfg.n_ite, F = d->n_frames, synd = d->cfg.enable_syndrome;
     const int P = (synd && d->poll_every > 0) ? d->poll_every : n_ite;
     const bool graphs = d->use_graphs && !d->prof_on;

@@ -104,6 +104,8 @@ struct qldpc_decoder {
     int *h_done;
     hipEvent_t e_ev[2];
     int use_graphs, graph_frames;
+    int persist, persist_blocks;     /* one cooperative launch per decode (qe_persist): enabled / co-resident workgroups (0 = not probed yet) */
+    int *e_ctl; int iters_pending;   /* control words of the one-launch decode (qe_xcd); its iteration count / fault flag are read back on demand */
     hipStream_t cap_stream;
     std::vector<hipGraphExec_t> e_graphs;   /* one per chunk of poll_every iterations */
     /* profiling */

@@ -22,11 +22,16 @@
 #ifndef QLDPC_KERNELS_EDGE_H
 #define QLDPC_KERNELS_EDGE_H
 
+#include <hip/hip_cooperative_groups.h>
+
 #include "qldpc_kernels.h"
 
 #define QE_THREADS 256
 #define QE_CPB 64                 /* checks per workgroup  */
 #define QE_MAX_EDGES (QE_CPB * 64)
+
+template <bool COH> __device__ __forceinline__ float qe_ld(const float *p);
+template <bool COH> __device__ __forceinline__ uint32_t qe_ldu(const uint32_t *p);
 
 /* convergence bookkeeping of one frame, all in global memory:
  *   unsat[f][ite]  OR over checks of the syndrome of the bits that existed when CN(ite) ran
@@ -42,20 +47,19 @@ __device__ __forceinline__ bool qe_converged(const int *__restrict__ unsat, int 
 
 /* ------------------------------------------------------------------ check nodes -------------- */
 
-template <int S, int FAM>
-__global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2c, float *__restrict__ c2v,
-                                                    const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
-                                                    const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
-                                                    int M, int E, int W, int *__restrict__ unsat, int unsat_stride, int ite,
-                                                    const int *__restrict__ done_at, qk_rule rule, int syndrome_only, const uint32_t *__restrict__ synd, int Wm)
+/* one chunk of QE_CPB checks of frame f; s_idx / s_val: QE_MAX_EDGES words of LDS each, s_unsat: one LDS int.  Every thread of the
+ * workgroup must call it (it synchronises the workgroup). */
+template <int S, int FAM, bool COH = false>
+__device__ __forceinline__ void qe_cn_chunk(int f, int chunk, int *s_idx, float *s_val, int *s_unsat_p,
+                                            const float *__restrict__ v2c, float *__restrict__ c2v,
+                                            const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                            const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
+                                            int M, int E, int W, int *__restrict__ unsat, int unsat_stride, int ite,
+                                            qk_rule rule, int syndrome_only, const uint32_t *__restrict__ synd, int Wm)
 {
-    __shared__ int s_idx[QE_MAX_EDGES];
-    __shared__ float s_val[QE_MAX_EDGES];
-    __shared__ int s_unsat;
-    const int f = blockIdx.y;
-    if (!syndrome_only && done_at[f] >= 0) return;      /* the final success-flag pass covers every frame */
+#define s_unsat (*s_unsat_p)
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * QE_CPB;
+    const int c0 = chunk * QE_CPB;
     const int c1 = min(M, c0 + QE_CPB);
     const int e0 = cn_ptr[c0], nE = cn_ptr[c1] - e0;
     const float *vin = v2c + (size_t)f * E;
@@ -66,9 +70,9 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
     for (int e = tid; e < nE; e += QE_THREADS) {
         const int slot = cn_tr[e0 + e];
         const int v = cn_var[e0 + e];
-        const uint32_t bit = (sw[v >> 5] >> (31 - (v & 31))) & 1u;
+        const uint32_t bit = (qe_ldu<COH>(sw + (v >> 5)) >> (31 - (v & 31))) & 1u;
         s_idx[e] = slot | (int)(bit << 31);
-        s_val[e] = syndrome_only ? 0.0f : vin[slot];
+        s_val[e] = syndrome_only ? 0.0f : qe_ld<COH>(vin + slot);
     }
     __syncthreads();
     /* phase B: one S-lane segment per check, butterfly all-reduce with wavefront shuffles */
@@ -128,6 +132,22 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
     if (!syndrome_only)
         for (int e = tid; e < nE; e += QE_THREADS) cout[s_idx[e] & 0x7fffffff] = s_val[e];
     if (tid == 0 && s_unsat) atomicOr(&unsat[(size_t)f * unsat_stride + ite], 1);
+#undef s_unsat
+}
+
+template <int S, int FAM>
+__global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2c, float *__restrict__ c2v,
+                                                    const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                                    const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
+                                                    int M, int E, int W, int *__restrict__ unsat, int unsat_stride, int ite,
+                                                    const int *__restrict__ done_at, qk_rule rule, int syndrome_only, const uint32_t *__restrict__ synd, int Wm)
+{
+    __shared__ int s_idx[QE_MAX_EDGES];
+    __shared__ float s_val[QE_MAX_EDGES];
+    __shared__ int s_unsat;
+    const int f = blockIdx.y;
+    if (!syndrome_only && done_at[f] >= 0) return;      /* the final success-flag pass covers every frame */
+    qe_cn_chunk<S, FAM>(f, blockIdx.x, s_idx, s_val, &s_unsat, v2c, c2v, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, syndrome_only, synd, Wm);
 }
 
 /* ------------------------------------------------------------------ variable nodes ----------- */
@@ -137,34 +157,22 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
  * Dynamic LDS: 256 * max_dv floats.  The convergence test of the PREVIOUS check pass is evaluated
  * here by every workgroup (same global words, so the same answer); workgroup 0 records it.
  */
-template <int MODE>
-__global__ __launch_bounds__(QE_THREADS) void qe_vn(const float *__restrict__ c2v0, const float *__restrict__ c2v1, int sel, int n_ite,
-                                                    const float *__restrict__ llr, float *__restrict__ v2c,
-                                                    uint32_t *__restrict__ sgn, uint32_t *__restrict__ hard, float *__restrict__ post_out,
-                                                    const int *__restrict__ vn_ptr, int N, int E, int W,
-                                                    const int *__restrict__ unsat, int unsat_stride, int ite, int depth, int check,
-                                                    int *__restrict__ done_at, int force)
+/* one chunk of QE_THREADS VNs of frame f; s_msg: QE_THREADS * max_dv floats of LDS; sel: which chk_to_var buffer to read.  Every thread
+ * of the workgroup must call it (it synchronises the workgroup). */
+template <int MODE, bool COH = false>
+__device__ __forceinline__ void qe_vn_chunk(int f, int chunk, float *s_msg, const float *__restrict__ c2v0, const float *__restrict__ c2v1, int sel,
+                                            const float *__restrict__ llr, float *__restrict__ v2c,
+                                            uint32_t *__restrict__ sgn, uint32_t *__restrict__ hard, float *__restrict__ post_out,
+                                            const int *__restrict__ vn_ptr, int N, int E, int W)
 {
-    extern __shared__ __align__(16) float s_msg[];
-    const int f = blockIdx.y;
-    if (!force) {
-        if (done_at[f] >= 0) return;
-        if (check && qe_converged(unsat, unsat_stride, f, ite, depth)) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) done_at[f] = ite;     /* iterations executed */
-            return;
-        }
-    }
     const int tid = threadIdx.x;
-    const int v0 = blockIdx.x * QE_THREADS;
+    const int v0 = chunk * QE_THREADS;
     const int v1 = min(N, v0 + QE_THREADS);
     const int sl0 = vn_ptr[v0], nS = vn_ptr[v1] - sl0;
-    /* chk_to_var is double-buffered by iteration parity so that the check pass which DETECTS convergence
-     * (it runs one iteration ahead) does not clobber the messages the posterior is made of */
-    if (sel < 0) sel = ((done_at[f] >= 0 ? done_at[f] : n_ite) - 1) & 1;
     const float *cin = (sel ? c2v1 : c2v0) + (size_t)f * E + sl0;
     float *vout = v2c + (size_t)f * E + sl0;
     if (MODE != QK_VN_FIRST) {
-        for (int k = tid; k < nS; k += QE_THREADS) s_msg[k] = cin[k];
+        for (int k = tid; k < nS; k += QE_THREADS) s_msg[k] = qe_ld<COH>(cin + k);
         __syncthreads();
     }
     const int v = v0 + tid;
@@ -192,6 +200,172 @@ __global__ __launch_bounds__(QE_THREADS) void qe_vn(const float *__restrict__ c2
     if (MODE != QK_VN_POST) {
         __syncthreads();
         for (int k = tid; k < nS; k += QE_THREADS) vout[k] = s_msg[k];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(QE_THREADS) void qe_vn(const float *__restrict__ c2v0, const float *__restrict__ c2v1, int sel, int n_ite,
+                                                    const float *__restrict__ llr, float *__restrict__ v2c,
+                                                    uint32_t *__restrict__ sgn, uint32_t *__restrict__ hard, float *__restrict__ post_out,
+                                                    const int *__restrict__ vn_ptr, int N, int E, int W,
+                                                    const int *__restrict__ unsat, int unsat_stride, int ite, int depth, int check,
+                                                    int *__restrict__ done_at, int force)
+{
+    extern __shared__ __align__(16) float s_msg[];
+    const int f = blockIdx.y;
+    if (!force) {
+        if (done_at[f] >= 0) return;
+        if (check && qe_converged(unsat, unsat_stride, f, ite, depth)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) done_at[f] = ite;     /* iterations executed */
+            return;
+        }
+    }
+    /* chk_to_var is double-buffered by iteration parity so that the check pass which DETECTS convergence
+     * (it runs one iteration ahead) does not clobber the messages the posterior is made of */
+    if (sel < 0) sel = ((done_at[f] >= 0 ? done_at[f] : n_ite) - 1) & 1;
+    qe_vn_chunk<MODE>(f, blockIdx.x, s_msg, c2v0, c2v1, sel, llr, v2c, sgn, hard, post_out, vn_ptr, N, E, W);
+}
+
+/* ------------------------------------------------------------------ one launch per decode ------------ */
+
+/*
+ * The whole decode of up to 8 blocks as ONE launch, ONE XCD PER BLOCK.
+ *
+ * A flooding iteration is two phases with an all-to-all hand-off in between; as launches that costs ~27 us per iteration for one
+ * 65 536-VN block, and a grid barrier across XCDs is no cheaper: their L2s are not coherent with each other, so either every word
+ * goes through the fabric (sc1 stores / loads: measured 446 us per block against 327 us with a launch per pass) or every barrier
+ * pays an L2 write-back and invalidate.  Inside ONE XCD the L2 IS the coherence point: plain stores land there and loads that bypass
+ * the CU's L1 (nt) see them.  So each workgroup reads the XCD it runs on (HW_REG_XCC_ID); the XCDs claim the blocks in order of
+ * arrival (block f is decoded by the workgroups of one XCD only -- that is read from the hardware, not assumed from blockIdx), up to
+ * `nb` workgroups per block stay resident on its 32 CUs, the rest of the grid exits at once.  The phases are the launches of
+ * run_edges() -- VN(first) | CN(0) VN(0) | CN(1) VN(1) ... | syndrome of the hard decisions -- separated by a barrier on a counter in
+ * that L2: every wave waits for its stores (s_waitcnt vmcnt(0)), workgroup barrier, one lane adds and polls.  The early exit is
+ * decided on the device (every workgroup evaluates the same flags after the barrier).  Every wait is bounded: a workgroup that never
+ * arrives sets *fault instead of hanging the grid, and the host then decodes with a launch per pass.
+ */
+#define QE_PERSIST_MAX_FRAMES 8
+#define QE_CTL_XCC 0          /* [8]  block claimed by each XCD (-1 free, -2 being claimed) */
+#define QE_CTL_NEXT 8         /*      next block to hand out                                */
+#define QE_CTL_RANK 16        /* [8]  workgroups that joined block f                        */
+#define QE_CTL_BAR 32         /* [8]  barrier counter of block f                            */
+#define QE_CTL_FAULT 48
+#define QE_CTL_ITERS 49       /*      max over blocks of the check passes executed          */
+#define QE_CTL_WORDS 64
+#define QE_SPIN_LIMIT (1u << 21)
+
+/* COH: data handed between workgroups of one XCD inside one launch: loads bypass the CU's L1 (served by the XCD's L2) */
+template <bool COH> __device__ __forceinline__ float qe_ld(const float *p)
+{
+    if constexpr (COH) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ uint32_t qe_ldu(const uint32_t *p)
+{
+    if constexpr (COH) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+__device__ __forceinline__ int qe_atomic_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+/* barrier among the `nb` workgroups of one block (all on one XCD): returns false if it timed out */
+__device__ __forceinline__ void qe_xcd_barrier(int *counter, int target, int *fault)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* every wave: its stores have reached the L2 */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (qe_atomic_ld(counter) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > QE_SPIN_LIMIT) { __hip_atomic_store(fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+
+template <int S, int FAM>
+__global__ __launch_bounds__(QE_THREADS) void qe_xcd(float *__restrict__ v2c, float *__restrict__ c2v0, float *__restrict__ c2v1,
+                                                     const float *__restrict__ llr, const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
+                                                     const int *__restrict__ cn_var, const int *__restrict__ vn_ptr,
+                                                     uint32_t *__restrict__ sgn, uint32_t *__restrict__ hard,
+                                                     int N, int M, int E, int W, int F, int nb, int n_ite, int enable_syndrome, int depth,
+                                                     int *__restrict__ unsat, int unsat_stride, int *__restrict__ done_at, qk_rule rule,
+                                                     const uint32_t *__restrict__ synd, int Wm, int *__restrict__ ctl)
+{
+    extern __shared__ __align__(16) float s_dyn[];      /* max(2 * QE_MAX_EDGES + 16 words, QE_THREADS * max_dv floats) */
+    __shared__ int s_role[2];                           /* block index, rank within the block's workgroups (-1: leave) */
+    __shared__ int s_done;
+    int *s_idx = reinterpret_cast<int *>(s_dyn);
+    float *s_val = s_dyn + QE_MAX_EDGES;
+    int *s_unsat = reinterpret_cast<int *>(s_dyn + 2 * QE_MAX_EDGES);
+    int *fault = ctl + QE_CTL_FAULT;
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        int f = -1;
+        int seen = __hip_atomic_load(ctl + QE_CTL_XCC + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == -1) {
+            int expect = -1;
+            if (__hip_atomic_compare_exchange_strong(ctl + QE_CTL_XCC + xcc, &expect, -2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                f = __hip_atomic_fetch_add(ctl + QE_CTL_NEXT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* this XCD takes the next block */
+                if (f >= F) f = 1 << 20;
+                __hip_atomic_store(ctl + QE_CTL_XCC + xcc, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else seen = expect;
+        }
+        if (f < 0) {
+            unsigned spins = 0;
+            while ((f = (seen >= 0 ? seen : qe_atomic_ld(ctl + QE_CTL_XCC + xcc))) < 0) { seen = -2; __builtin_amdgcn_s_sleep(1); if (++spins > QE_SPIN_LIMIT) { f = 1 << 20; break; } }
+        }
+        int rank = -1;
+        if (f < F) {
+            rank = __hip_atomic_fetch_add(ctl + QE_CTL_RANK + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rank >= nb) rank = -1;
+        }
+        s_role[0] = f; s_role[1] = rank;
+        s_done = -1;
+    }
+    __syncthreads();
+    const int f = s_role[0], me = s_role[1];
+    if (me < 0) return;
+    int *bar = ctl + QE_CTL_BAR + f;
+    int round = 0;
+    const int nCN = (M + QE_CPB - 1) / QE_CPB, nVN = (N + QE_THREADS - 1) / QE_THREADS;
+    /* decoder reset + iteration 0's variable-node pass (chk_to_var == 0) */
+    for (int i = me * QE_THREADS + threadIdx.x; i < unsat_stride; i += nb * QE_THREADS) __hip_atomic_store(unsat + (size_t)f * unsat_stride + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int it = me; it < nVN; it += nb) { qe_vn_chunk<QK_VN_FIRST, true>(f, it, s_dyn, c2v0, c2v1, 0, llr, v2c, sgn, hard, nullptr, vn_ptr, N, E, W); __syncthreads(); }
+    qe_xcd_barrier(bar, ++round * nb, fault);
+    int ite = 0;
+    for (; ite < n_ite; ite++) {
+        for (int it = me; it < nCN; it += nb) {
+            qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, v2c, (ite & 1) ? c2v1 : c2v0, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, 0, synd, Wm);
+            __syncthreads();
+        }
+        qe_xcd_barrier(bar, ++round * nb, fault);
+        /* AFF3CT's stop rule on the flags the check pass left: the same words for every workgroup of the block */
+        if (threadIdx.x == 0 && enable_syndrome && ite >= depth) {
+            bool conv = true;
+            for (int k = 0; k < depth; k++) conv = conv && qe_atomic_ld(unsat + (size_t)f * unsat_stride + ite - k) == 0;
+            if (conv) s_done = ite;      /* iterations executed */
+        }
+        __syncthreads();
+        if (s_done >= 0 || qe_atomic_ld(fault)) break;
+        const bool last = ite == n_ite - 1;
+        for (int it = me; it < nVN; it += nb) {
+            if (last) qe_vn_chunk<QK_VN_POST, true>(f, it, s_dyn, c2v0, c2v1, ite & 1, llr, v2c, sgn, hard, nullptr, vn_ptr, N, E, W);
+            else qe_vn_chunk<QK_VN_NORMAL, true>(f, it, s_dyn, c2v0, c2v1, ite & 1, llr, v2c, sgn, hard, nullptr, vn_ptr, N, E, W);
+            __syncthreads();
+        }
+        qe_xcd_barrier(bar, ++round * nb, fault);
+    }
+    /* success flag: syndrome of the final hard decisions into the last slot; iteration count */
+    for (int it = me; it < nCN; it += nb) {
+        qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, v2c, c2v0, cn_ptr, cn_tr, cn_var, hard, M, E, W, unsat, unsat_stride, n_ite + 1, rule, 1, synd, Wm);
+        __syncthreads();
+    }
+    if (me == 0 && threadIdx.x == 0) {
+        done_at[f] = s_done;
+        atomicMax(ctl + QE_CTL_ITERS, ite < n_ite ? ite + 1 : n_ite);
     }
 }
 

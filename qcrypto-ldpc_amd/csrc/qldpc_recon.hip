@@ -45,6 +45,9 @@ struct recon_entry {
     int *d_iters, *d_ok;  /* [max_blocks] */
     int *d_nch;           /* [max_blocks] channel VNs per frame (block length) */
     int *d_np;            /* [max_blocks] punctured parity VNs per frame */
+    /* one pinned host block and one device block per direction: a decode is ONE copy in and ONE copy out */
+    uint32_t *h_in, *d_in;     /* keys [n][Wk] | disclosed parity [n][Wm] | |LLR| [n] | block length [n] | punctured [n] */
+    uint32_t *h_res, *d_res;   /* decoded words [n][Wn] | iterations [n] | success [n] */
 };
 
 struct qldpc_recon {
@@ -178,6 +181,9 @@ static void entry_free(recon_entry &e)
     qldpc_code_free(e.code);
     (void)hipFree(e.d_cls); (void)hipFree(e.d_key); (void)hipFree(e.d_disc); (void)hipFree(e.d_bits); (void)hipFree(e.d_erase); (void)hipFree(e.d_out);
     (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok); (void)hipFree(e.d_nch); (void)hipFree(e.d_np);
+    (void)hipFree(e.d_in); (void)hipFree(e.d_res);
+    if (e.h_in) (void)hipHostFree(e.h_in);
+    if (e.h_res) (void)hipHostFree(e.h_res);
 }
 
 extern "C" void qldpc_recon_free(qldpc_recon *r)
@@ -346,6 +352,10 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     alloc((void **)&e.d_ok, sizeof(int) * (size_t)B);
     alloc((void **)&e.d_nch, sizeof(int) * (size_t)B);
     alloc((void **)&e.d_np, sizeof(int) * (size_t)B);
+    alloc((void **)&e.d_in, sizeof(uint32_t) * (size_t)B * (Wk + Wm + 3));
+    alloc((void **)&e.d_res, sizeof(uint32_t) * (size_t)B * (Wn + 2));
+    if (!rc && hipHostMalloc((void **)&e.h_in, sizeof(uint32_t) * (size_t)B * (Wk + Wm + 3)) != hipSuccess) rc = QLDPC_ENOMEM;
+    if (!rc && hipHostMalloc((void **)&e.h_res, sizeof(uint32_t) * (size_t)B * (Wn + 2)) != hipSuccess) rc = QLDPC_ENOMEM;
     if (!rc) {
         std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* parity VNs are disclosed; key VNs past a block's length are pinned per frame */
         for (int i = 0; i < K; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
@@ -462,42 +472,45 @@ static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *
     HIPCHK(hipSetDevice(r->cfg.device));
     recon_entry *e;
     if ((rc = get_entry(r, K, M, &e))) return rc;
-    std::vector<uint32_t> keys((size_t)n * Wk, 0u), disc((size_t)n * Wm, 0u), outw((size_t)n * Wn);
-    std::vector<float> mag((size_t)n);
-    std::vector<int> np((size_t)n);
+    /* staging: everything Bob's side needs, packed into the entry's pinned block -> one copy; the results come back the same way */
+    uint32_t *h_keys = e->h_in, *h_disc = h_keys + (size_t)n * Wk;
+    float *h_mag = reinterpret_cast<float *>(h_disc + (size_t)n * Wm);
+    int *h_nch = reinterpret_cast<int *>(h_mag + n), *h_np = h_nch + n;
+    uint32_t *d_keys = e->d_in, *d_disc = d_keys + (size_t)n * Wk;
+    float *d_mag = reinterpret_cast<float *>(d_disc + (size_t)n * Wm);
+    int *d_nch = reinterpret_cast<int *>(d_mag + n), *d_np = d_nch + n;
+    memset(h_keys, 0, sizeof(uint32_t) * (size_t)n * (Wk + Wm));
     bool any_punct = false;
     for (int i = 0; i < n; i++) {
         const int Wkey = (key_bits[i] + 31) / 32;
-        memcpy(keys.data() + (size_t)i * Wk, key[i], sizeof(uint32_t) * (size_t)Wkey);
-        np[(size_t)i] = (int)msgs[i]->n_punct;
-        any_punct = any_punct || np[(size_t)i] != 0;
-        memcpy(disc.data() + (size_t)i * Wm, parity[i], sizeof(uint32_t) * (size_t)((M - np[(size_t)i] + 31) / 32));
-        mag[(size_t)i] = qldpc_bsc_llr(clamp_qber(qber[i]));
+        memcpy(h_keys + (size_t)i * Wk, key[i], sizeof(uint32_t) * (size_t)Wkey);
+        h_np[i] = (int)msgs[i]->n_punct;
+        h_nch[i] = key_bits[i];
+        any_punct = any_punct || h_np[i] != 0;
+        memcpy(h_disc + (size_t)i * Wm, parity[i], sizeof(uint32_t) * (size_t)((M - h_np[i] + 31) / 32));
+        h_mag[i] = qldpc_bsc_llr(clamp_qber(qber[i]));
     }
-    HIPCHK(hipMemcpy(e->d_key, keys.data(), sizeof(uint32_t) * keys.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_disc, disc.data(), sizeof(uint32_t) * disc.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_mag, mag.data(), sizeof(float) * mag.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_nch, key_bits, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_np, np.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(rk_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n), dim3(256), 0, 0, e->d_key, e->d_disc, e->d_nch, e->d_np, e->d_bits, e->d_erase, Wk, Wn, Wm, M);
+    HIPCHK(hipMemcpyAsync(e->d_in, e->h_in, sizeof(uint32_t) * (size_t)n * (Wk + Wm + 3), hipMemcpyHostToDevice, 0));
+    hipLaunchKernelGGL(rk_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n), dim3(256), 0, 0, d_keys, d_disc, d_nch, d_np, e->d_bits, e->d_erase, Wk, Wn, Wm, M);
     HIPCHK(hipGetLastError());
-    if ((rc = qldpc_load_bits_short_dev(e->dec, e->d_bits, e->d_mag, e->d_cls, e->d_nch, n))) return rc;
+    if ((rc = qldpc_load_bits_short_dev(e->dec, e->d_bits, d_mag, e->d_cls, d_nch, n))) return rc;
     if (any_punct && (rc = qldpc_load_erasures_dev(e->dec, e->d_erase, n))) return rc;
     if ((rc = qldpc_run(e->dec))) return rc;
-    if ((rc = qldpc_fetch_packed_dev(e->dec, e->d_out))) return rc;
-    if ((rc = qldpc_fetch_status_dev(e->dec, e->d_iters, e->d_ok))) return rc;
+    uint32_t *d_outw = e->d_res;
+    int *d_it = reinterpret_cast<int *>(d_outw + (size_t)n * Wn), *d_okf = d_it + n;
+    if ((rc = qldpc_fetch_packed_dev(e->dec, d_outw))) return rc;
+    if ((rc = qldpc_fetch_status_dev(e->dec, d_it, d_okf))) return rc;
+    HIPCHK(hipMemcpyAsync(e->h_res, e->d_res, sizeof(uint32_t) * (size_t)n * (Wn + 2), hipMemcpyDeviceToHost, 0));
     if ((rc = qldpc_sync(e->dec))) return rc;
-    std::vector<int> it((size_t)n), ok((size_t)n);
-    HIPCHK(hipMemcpy(outw.data(), e->d_out, sizeof(uint32_t) * outw.size(), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(it.data(), e->d_iters, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ok.data(), e->d_ok, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    const uint32_t *outw_p = e->h_res;
+    const int *it = reinterpret_cast<const int *>(outw_p + (size_t)n * Wn), *ok = it + n;
     for (int i = 0; i < n; i++) {
         const int kb = key_bits[i], Wkey = (kb + 31) / 32;
-        const uint32_t *o = outw.data() + (size_t)i * Wn;
+        const uint32_t *o = outw_p + (size_t)i * Wn;
         uint32_t *kw = key[i];
-        const bool good = ok[(size_t)i] && qldpc_crc32_words(o, kb) == msgs[i]->crc32;
+        const bool good = ok[i] && qldpc_crc32_words(o, kb) == msgs[i]->crc32;
         *status[i] = good ? QLDPC_OK : QLDPC_EDECODE;
-        if (iterations[i]) *iterations[i] = it[(size_t)i];
+        if (iterations[i]) *iterations[i] = it[i];
         int flips = 0;
         if (good) {
             for (int w = 0; w < Wkey; w++) {

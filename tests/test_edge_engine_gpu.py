@@ -143,3 +143,23 @@ def test_edge_engine_unsupported_requests_say_so(q, peg):
     if big.max_cn_degree > 64:
         with pytest.raises(q.QldpcError):
             q.Decoder(big, big.N, 5, rule="MS", n_frames=1, engine="edges")
+
+
+@pytest.mark.parametrize("wgs", ["", "100000"])
+def test_one_launch_decode_one_xcd_per_block(q, O, torch, peg, monkeypatch, wgs):
+    """QLDPC_EDGE_PERSIST=1 (opt-in, csrc/qldpc_kernels_edge.h qe_xcd): the whole decode in one launch, every block on the XCD that
+    claimed it, grid barriers on that XCD's L2, early exit decided on the device -- the same bits, iteration counts and flags as the
+    launch-per-pass path and the oracle.  With more workgroups per block asked for than an XCD can hold the barriers time out (bounded
+    waits: the grid drains), the decoder says so and repeats the decode with a launch per pass: still the same answers."""
+    code, og = peg
+    monkeypatch.setenv("QLDPC_EDGE_PERSIST", "1")
+    if wgs:
+        monkeypatch.setenv("QLDPC_EDGE_WGS", wgs)
+    for F, rule, param in ((1, "NMS", 0.75), (5, "OMS", 0.35), (8, "MS", 0.0)):
+        llr = bsc(np.random.default_rng(200 + F), F, 1008, 0.055, 2.7)
+        ref = O.decode(og, llr, rule, param, 25, n_threads=4)
+        dec = q.Decoder(code, 1008, 25, rule=rule, rule_param=param, n_frames=F, engine="edges")
+        for _ in range(2):
+            hard, it, ok, post = run(q, torch, dec, llr)
+            assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+            assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()
