@@ -383,7 +383,8 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
     ld->rateIndex = msg->rate_index; ld->codeK = msg->code_k; ld->codeM = msg->code_m; ld->iterations = iterations;
-    printf("ldpc: epoch %08x: decoded %d key bits in %d iterations, %d errors corrected, %d bits leaked\n", pb->startEpoch, pb->workbits, iterations, corrected, leaked);
+    printf("ldpc: epoch %08x: decoded %d key bits in %d iterations, %d errors corrected, %d bits leaked (code sets built so far: %ld)\n", pb->startEpoch, pb->workbits,
+           iterations, corrected, leaked, qldpc_recon_entries_created(g_recon));
     fflush(stdout);
     pb->correctedErrors = corrected;
     pb->leakageBits += leaked;

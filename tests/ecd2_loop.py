@@ -14,6 +14,30 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))      # lives in tests/: it runs 
 from ecd2_loopback import run_loopback  # noqa: E402
 
 binary = os.path.join(ROOT, "oracle", "_ref", sys.argv[1])
+if sys.argv[2].startswith("single="):
+    # ONE daemon pair, many blocks of different length: every block must end with identical keys, and the number of
+    # (code, encoder, decoder) sets the follower has built must be the same after the last block as after ldpc_init
+    nblk = int(sys.argv[2].split("=", 1)[1])
+    rng = np.random.default_rng(99)
+    sizes = []
+    while len(sizes) < 2 * nblk:
+        x, y = int(rng.integers(1500, 16000)), int(rng.integers(1500, 16000))
+        if (x + y) % 32:
+            sizes += [x, y]
+    a = [rng.integers(0, 2, n).astype(np.uint8) for n in sizes]
+    b = [x ^ (rng.random(x.size) < rng.uniform(0.01, 0.05)) for x in a]
+    d = pathlib.Path(tempfile.mkdtemp())
+    out = run_loopback(binary, d, a, b, extra_args=["-L", "1,g"] + sys.argv[3:], blocks=[2] * nblk, timeout=40 + 2 * nblk, cmd_gaps=(60.0, 0.12))
+    okb = sum(1 for v in out["finals"].values() if v[0] is not None and v[1] is not None and v[0]["nbits"] == v[1]["nbits"] and (v[0]["words"] == v[1]["words"]).all())
+    built = [int(x) for x in re.findall(r"code sets built so far: (\d+)", out["b_log"])]
+    ready = re.search(r"engine ready, (\d+) code", out["b_log"])
+    fell = out["b_log"].count("falling back to cascade")
+    print("one daemon pair, %d blocks of %d..%d bits: %d with identical final keys (%d via the cascade fallback), code sets at init %s, after the last block %s (min %s)" % (
+        nblk, min(sizes) * 2, max(sizes) * 2, okb, fell, ready.group(1) if ready else "?", built[-1] if built else "?", min(built) if built else "?"), flush=True)
+    if okb != nblk:
+        for side in "ab":
+            open(os.path.join(ROOT, "gpurun_out", "loop_single_%s.log" % side), "w").write(out[side + "_log"])
+    sys.exit(0 if okb == nblk and built and ready and built[-1] == int(ready.group(1)) else 1)
 runs = int(sys.argv[2])
 env = {"ECD2_LDPC": "1"}
 for kv in sys.argv[3:]:
