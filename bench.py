@@ -383,7 +383,7 @@ def main():
                                   kernel_ms=sum(s_["total_ms"] for s_ in hot), all_kernels_ms=kern_ms,
                                   achieved=sum(s_["alg_bytes"] for s_ in hot) / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9,
                                   frac=sum(s_["alg_bytes"] for s_ in hot) / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9 / HBM_PEAK_GBS),
-                    workload="%d epochs x %d bits, QBER ~ U[0.5 %%, 6 %%] (seed 42), rate per epoch from {0.5, 0.7, 0.8, 0.9} (f = 1.4, kept 0.035 (65536/K)^0.4 "
+                    workload="%d epochs x %d bits, QBER ~ U[0.5 %%, 6 %%] (seed 42), rate per epoch from {0.5, 0.7, 0.8, 0.9} (f = 1.4, kept 0.021 - 0.035 (by mother rate) x (65536/K)^0.4 "
                              "from capacity), mother code K = 57344 shortened + punctured per epoch, flooding SPA, blocks of one code batched" % (epochs_n, key_bits))
 
     cfg3 = cfg5 = None

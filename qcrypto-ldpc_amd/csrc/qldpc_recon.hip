@@ -278,7 +278,8 @@ extern "C" int qldpc_recon_profile_read(qldpc_recon *r, qldpc_kernel_stat *out, 
 /*
  * Rate choice, code dimensions and puncturing of a block (BS/src/main.cpp:29-34,235-311).  The QBER estimate is clamped to
  * [0.001, 0.25] first: the daemon's localError is exactly 0 when the test sample held no error (qber_estim.c:26).
- *   target rate  R* = min( 1 / (1 + f h(q)),  1 - h(q) - rate_gap (65536 / K)^0.4 )   the harness's min_cr, kept away from capacity
+ *   target rate  R* = min( 1 / (1 + f h(q)),  1 - h(q) - rate_gap (65536 / K)^0.4 c(R) )   the harness's min_cr, kept away from capacity;
+ *                c(R) = 0.6 for mother rates <= 0.75, 0.9 up to 0.85, 1 above
  *   table rate   R  = largest entry <= R*                                  (BS/src/main.cpp:241-266)
  *   code         K >= key_bits information VNs (mother code, shortened), M = round(K (1 - R) / R) parity VNs
  *   disclosed    d = ceil(key_bits (1 / R* - 1)) parity bits, the other p = M - d are punctured (parity_bits_to_punct with the block's
@@ -299,12 +300,20 @@ extern "C" int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, 
      * 0.035 for K = 65 536, 0.042 for 32 768, 0.06 for 16 384 and 8 192 (tools/punct_probe.py) -- rate_gap (65536 / K)^0.4 covers them */
     int K0, M0;
     code_dims(r->cfg, key_bits, 0.5, &K0, &M0);
-    const double gap = (double)r->gap * pow(65536.0 / (double)K0, 0.4);
-    double need = qldpc_min_code_rate(q, r->cfg.efficiency);
-    if (1.0 - h - gap < need) need = 1.0 - h - gap;
+    const double gap_len = (double)r->gap * pow(65536.0 / (double)K0, 0.4);
+    /* ... and with the rate of the mother code: the low-rate mothers decode punctured to within 0.02 of capacity (FER 0 / 128 at 0.015 -
+     * 0.02 for rates 0.5 and 0.7), rate 0.8 needs 0.03 and rate 0.9 0.035 (tools/punct_probe.py, gpurun logs punct_c / punct_e): the
+     * table entry is the highest rate that fits under ITS OWN target */
     int idx = -1;
-    for (int i = 0; i < r->cfg.n_rates; i++) if (r->cfg.rates[i] <= need) idx = i;
-    if (idx < 0) { qldpc_set_error("recon_plan: QBER %.4f needs rate <= %.3f, below the table", (double)qber, need); return QLDPC_EUNSUPPORTED; }
+    double need = 0.0;
+    for (int i = 0; i < r->cfg.n_rates; i++) {
+        const double R = r->cfg.rates[i];
+        const double gap = gap_len * (R <= 0.75 ? 0.6 : (R <= 0.85 ? 0.9 : 1.0));
+        double t = qldpc_min_code_rate(q, r->cfg.efficiency);
+        if (1.0 - h - gap < t) t = 1.0 - h - gap;
+        if (R <= t) { idx = i; need = t; }
+    }
+    if (idx < 0) { qldpc_set_error("recon_plan: QBER %.4f is above what the rate table covers", (double)qber); return QLDPC_EUNSUPPORTED; }
     int K, M;
     code_dims(r->cfg, key_bits, r->cfg.rates[idx], &K, &M);
     int p = 0;

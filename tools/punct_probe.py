@@ -48,7 +48,7 @@ for Km in [int(x) for x in os.environ.get("MOTHERS", "65536,53248").split(",")]:
                 print("K_m %d R %.1f q %.3f: needs %d parity bits, mother has %d" % (Km, R, qber, d, M))
                 continue
             if code is None:
-                code = q.Code.ira(N, Km, 0.125, 11, 3, 7)
+                code = q.Code.ira_peg(N, Km, depth=int(os.environ["PEG"]), seed=7) if os.environ.get("PEG") else q.Code.ira(N, Km, 0.125, 11, 3, 7)
                 enc = q.Encoder(code, "IRA")
                 dec = q.Decoder(code, Km, int(os.environ.get("N_ITE", "50")), rule=RULE, rule_param=ALPHA, n_frames=F)
             info = np.zeros((F, Km), np.uint8)

@@ -17,14 +17,15 @@ q = _qldpc_loader.load()
 EPOCHS = int(os.environ.get("EPOCHS", "512"))
 KEY_BITS = int(os.environ.get("KEY_BITS", "52429"))
 BATCH = int(os.environ.get("BATCH", "64"))
-rng = np.random.default_rng(42)
+rng = np.random.default_rng(int(os.environ.get("SEED", "42")))
 qbers = rng.uniform(0.005, 0.06, EPOCHS).astype(np.float32)
 alice = rng.integers(0, 2, (EPOCHS, KEY_BITS)).astype(np.uint8)
 bob = alice ^ (rng.random((EPOCHS, KEY_BITS)) < qbers[:, None])
 aw, bw = q.pack_bits(alice), q.pack_bits(bob)
 
 SCHED = os.environ.get("SCHEDULE", "flooding")
-ra, rb = q.Recon(max_blocks=BATCH), q.Recon(max_blocks=BATCH, schedule=SCHED)
+GAP = float(os.environ["RATE_GAP"]) if os.environ.get("RATE_GAP") else None
+ra, rb = q.Recon(max_blocks=BATCH, rate_gap=GAP), q.Recon(max_blocks=BATCH, schedule=SCHED, rate_gap=GAP)
 plans = [ra.plan(KEY_BITS, p) for p in qbers]
 groups = {}
 for i, m in enumerate(plans):
