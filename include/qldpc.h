@@ -196,6 +196,8 @@ void qldpc_decoder_free(qldpc_decoder *dec);
 int qldpc_decoder_set_stream(qldpc_decoder *dec, void *hip_stream);
 int qldpc_decoder_reset(qldpc_decoder *dec);
 size_t qldpc_decoder_device_bytes(const qldpc_decoder *dec);   /* HBM held by this decoder        */
+/* Allocate now the buffers the load calls would otherwise allocate on first use (per-frame erasure ballots). */
+int qldpc_decoder_reserve(qldpc_decoder *dec);
 
 /* AFF3CT mirror, host pointers: Y_N[n_frames][N] -> V_K[n_frames][K] (one int per bit). Synchronous. */
 int qldpc_decode_siho(qldpc_decoder *dec, const float *Y_N, int *V_K, int n_frames);

@@ -102,6 +102,7 @@ _sig("qldpc_decoder_free", None, [_vp])
 _sig("qldpc_decoder_set_stream", C.c_int, [_vp, _vp])
 _sig("qldpc_decoder_reset", C.c_int, [_vp])
 _sig("qldpc_decoder_device_bytes", C.c_size_t, [_vp])
+_sig("qldpc_decoder_reserve", C.c_int, [_vp])
 _sig("qldpc_decode_siho", C.c_int, [_vp, _fp, _ip, C.c_int])
 _sig("qldpc_load_llr_dev", C.c_int, [_vp, _vp, C.c_int])
 _sig("qldpc_load_bits_dev", C.c_int, [_vp, _vp, _vp, _vp, C.c_int])

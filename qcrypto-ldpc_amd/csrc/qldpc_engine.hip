@@ -1129,6 +1129,18 @@ extern "C" int qldpc_load_erasures_dev(qldpc_decoder *d, const uint32_t *d_erase
     return QLDPC_OK;
 }
 
+/* allocate now what the load calls would allocate on first use (the per-frame erasure ballots of the coded-LLR form), so that a
+ * caller who must not allocate later -- the daemon after ldpc_init -- can say so */
+extern "C" int qldpc_decoder_reserve(qldpc_decoder *d)
+{
+    if (!d) return QLDPC_EINVAL;
+    HIPCHK(hipSetDevice(d->device));
+    view_reset(d);
+    int rc;
+    if (d->engine != QLDPC_ENGINE_EDGES && d->d_ybits && !d->d_ebits && (rc = dev_alloc(d, &d->d_ebits, (size_t)d->G0 * d->N * d->V))) return rc;
+    return QLDPC_OK;
+}
+
 /* s = H x on the device for packed words (Alice's side of the syndrome form; also a codeword test) */
 extern "C" int qldpc_syndrome_dev(qldpc_decoder *d, const uint32_t *d_bits, uint32_t *d_synd_bits, int n_frames)
 {

@@ -776,7 +776,8 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
  * 1-D grid of 8 * ceil(G / 8) * bx workgroups.  Workgroups are dealt round-robin to the 8 XCDs, whose L2s are not coherent with
  * each other: the ballots the variable-node pass just wrote come in over the fabric, so ALL workgroups of a group are placed on ONE
  * XCD (g = id % 8 + 8 * (id / 8 / bx)) and its 8 N bytes of ballots cross the fabric once instead of eight times (measured on the
- * config-2 batch: 68 -> 58 us per pass; what remains is the tag-lookup rate of 64-address gathers, not bytes).
+ * config-2 batch: 68 -> 58 us per pass; what remains is the tag-lookup rate of 64-address gathers, not bytes.  A VN-major form with
+ * the syndrome words of a group in LDS (one 1024-thread workgroup per group, ds_xor_b64 per edge) was measured at 84 us: slower).
  */
 template <int V>
 __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_var_t, int max_dc, int M, int N,

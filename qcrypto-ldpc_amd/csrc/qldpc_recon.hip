@@ -348,6 +348,7 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
         dc.schedule = r->cfg.schedule == QLDPC_SCHED_HLAYERED ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING; dc.rule = r->cfg.rule; dc.rule_param = r->cfg.rule_param; dc.n_ite = r->cfg.n_ite;
         dc.enable_syndrome = 1; dc.syndrome_depth = 1; dc.max_frames = B; dc.device = r->cfg.device;
         rc = qldpc_decoder_create(e.code, K, nullptr, &dc, &e.dec);
+        if (!rc) rc = qldpc_decoder_reserve(e.dec);      /* nothing is allocated per block later */
     }
     auto alloc = [&](void **ptr, size_t bytes) { if (!rc && hipMalloc(ptr, bytes) != hipSuccess) rc = QLDPC_ENOMEM; };
     alloc((void **)&e.d_cls, (size_t)N);

@@ -347,6 +347,64 @@ __global__ __launch_bounds__(256) void c2_vn(const c2_rec* __restrict__ S, u64* 
     if (UN * DVMAX <= 64 && dst != og) *dst = mine;
 }
 
+// D: mixed layouts.  var_to_chk stays VN-major (written contiguously by the VN pass, gathered by the CN pass), chk_to_var becomes CN-major
+// (written contiguously by the CN pass, gathered by the VN pass through cnslot): every pass has ONE gather and ONE stream instead of
+// gather + scatter (CN) and stream + stream (VN).  Same 4E + N rows.
+__global__ __launch_bounds__(256) void d_cn(const float* __restrict__ v2c, float* __restrict__ c2v, const int* __restrict__ slot, int M, size_t E)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bpg = (M + 3) / 4;
+    const int g = blockIdx.x / bpg, c = (blockIdx.x % bpg) * 4 + wave;
+    if (c >= M) return;
+    int s[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) s[k] = slot[c * DC + k];
+    const float* in = v2c + (size_t)g * E * 64 + lane; float* out = c2v + ((size_t)g * E + (size_t)c * DC) * 64 + lane;
+    float v[DC], o[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) v[k] = ldnt(in + (size_t)s[k] * 64);
+    fold(v, o);
+#pragma unroll
+    for (int k = 0; k < DC; k++) stnt(out + (size_t)k * 64, o[k]);
+}
+template <int DVMAX, int UN>
+__global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const float* __restrict__ llr, float* __restrict__ v2c, const int* __restrict__ vptr,
+                                            const int* __restrict__ cnslot, int N, size_t E, int v_lo, int v_hi)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nv = v_hi - v_lo;
+    const int bpg = (nv + 4 * UN - 1) / (4 * UN);
+    const int g = blockIdx.x / bpg;
+    const int i0 = ((blockIdx.x % bpg) * 4 + wave) * UN;
+    if (i0 >= nv) return;
+    const float* in = c2v + (size_t)g * E * 64 + lane;
+    int vv[UN], s0[UN], d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { vv[u] = v_lo + min(i0 + u, nv - 1); s0[u] = vptr[vv[u]]; d[u] = vptr[vv[u] + 1] - s0[u]; }
+    int e[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];
+    }
+    float m[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) m[u][k] = ldnt(in + (size_t)e[u][k] * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) sum += m[u][k];
+        const float t = ldnt(llr + ((size_t)g * N + vv[u]) * 64 + lane) + sum;
+        float* out = v2c + ((size_t)g * E + s0[u]) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) stnt(out + (size_t)k * 64, t - m[u][k]);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int M = 13107, K = 52429, N = M + K, G = argc > 1 ? atoi(argv[1]) : 64;
@@ -446,6 +504,15 @@ int main(int argc, char** argv)
             best = std::min(best, t1 + t2);
         }
         printf("iteration: C2 %.3f ms (%.1f %% vs A %.3f ms)\n", best, 100.0 * best / (acn + avn) - 100.0, acn + avn);
+    }
+
+    {
+        const int n11 = 6553;
+        float dcn = timeit("D cn  gather v2c, stream c2v (2E)", 2.0 * E, [&] { d_cn<<<gcn, 256>>>(v2c, c2v, d_slot, M, E); });
+        float dvn = timeit("D vn  gather c2v, stream v2c (2E+N)", 2.0 * E + N, [&] {
+            d_vn<12, 2><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+            d_vn<4, 4><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
+        printf("iteration: D %.3f ms (%.1f %% vs A %.3f ms)\n", dcn + dvn, 100.0 * (dcn + dvn) / (acn + avn) - 100.0, acn + avn);
     }
     printf("iteration: B' %.3f ms (%.1f %%)\n", b2cn + b2vn, 100.0 * (b2cn + b2vn) / (acn + avn) - 100.0);
     printf("iteration: A %.3f ms   B %.3f ms (%.1f %%)   B(nt) %.3f ms (%.1f %%)\n", acn + avn, bcn + bvn, 100.0 * (bcn + bvn) / (acn + avn) - 100.0,
