@@ -487,10 +487,17 @@ template <int V>
 static int synd_pass(qldpc_decoder *d, const u64 *mask, int skip_done)
 {
     prof_scope ps(d, KS_SYND, (double)d->E * 8.0 * d->G * V);
-    const int bx = std::max(1, std::min((d->M + 255) / 256, 4096 / std::max(1, d->G)));
     const int g8 = (d->G + 7) / 8 * 8;      /* groups rounded up to the XCD count: see qk_syndrome */
-    hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)(g8 * bx)), dim3(256), 0, d->stream, mask, d->d_cn_var_t, d->max_dc, d->M, d->N,
-                       d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr, d->G, bx);
+    /* early-exit passes go in two launches: an eighth of the checks first; the second launch returns at once for every group in which
+     * all running frames already show an unsatisfied check (measured: 1.17 -> 0.69 ms of syndrome passes per config-2 step).  The closing success-flag pass
+     * (skip_done = 0) and small codes take one launch. */
+    const int Mp = (skip_done && d->M >= 4096) ? ((d->M / 8 + 255) / 256) * 256 : d->M;
+    for (int part = 0; part < (Mp < d->M ? 2 : 1); part++) {
+        const int lo = part ? Mp : 0, hi = part ? d->M : Mp;
+        const int bx = std::max(1, std::min((hi - lo + 255) / 256, 4096 / std::max(1, d->G)));
+        hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)(g8 * bx)), dim3(256), 0, d->stream, mask, d->d_cn_var_t, d->max_dc, d->M, d->N,
+                           d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr, d->G, bx, lo, hi, part);
+    }
     LAUNCHCHK();
     return QLDPC_OK;
 }

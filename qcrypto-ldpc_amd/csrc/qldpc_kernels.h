@@ -781,18 +781,28 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
  */
 template <int V>
 __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask, const int *__restrict__ cn_var_t, int max_dc, int M, int N,
-                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done, const u64 *__restrict__ synd, int G, int bx)
+                                                   u64 *__restrict__ unsat, const u64 *__restrict__ done, int skip_done, const u64 *__restrict__ synd, int G, int bx,
+                                                   int c_lo, int c_hi, int gated)
 {
     const int id = blockIdx.x;
     const int g = (id & 7) + 8 * ((id >> 3) / bx);
     const int chunk = (id >> 3) % bx;
     if (g >= G) return;
     if (skip_done && qk_group_done<V>(done, g)) return;
+    if (gated) {
+        /* the pass runs in two launches: checks [0, M/8) first, the rest here.  If every frame of the group that is still running already
+         * shows an unsatisfied check, the remaining checks cannot change any verdict: in the iterations before the first convergence
+         * (nine of ~fourteen at QBER 2 %) this launch returns at once */
+        bool settled = true;
+#pragma unroll
+        for (int j = 0; j < V; j++) settled = settled && ((__hip_atomic_load(&unsat[(size_t)g * V + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | done[(size_t)g * V + j]) == ~0ull);
+        if (settled) return;
+    }
     const u64 *mg = mask + (size_t)g * N * V;
     u64 acc[V];
 #pragma unroll
     for (int j = 0; j < V; j++) acc[j] = 0;
-    for (int c = chunk * blockDim.x + threadIdx.x; c < M; c += bx * blockDim.x) {
+    for (int c = c_lo + chunk * blockDim.x + threadIdx.x; c < c_hi; c += bx * blockDim.x) {
         u64 s[V];
 #pragma unroll
         for (int j = 0; j < V; j++) s[j] = synd ? synd[((size_t)g * M + c) * V + j] : 0ull;      /* H x must equal the target syndrome */
