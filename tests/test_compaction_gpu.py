@@ -138,3 +138,19 @@ def test_auto_mode_and_refusals(q, torch, peg):
         dec.run()
         assert dec.last_run_stats()["compactions"] == 0
         dec.fetch_post()
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_syndrome_depth_counters_move_with_their_frames(q, O, torch, peg, depth):
+    """AFF3CT's syndrome_depth > 1 keeps a per-frame count of consecutive zero syndromes (cur_syndrome_depth); a frame that is dealt
+    into another group in the middle of such a run must take its count along"""
+    code, og = peg
+    rng = np.random.default_rng(50 + depth)
+    F, N = 700, 1008
+    y, _ = frames(rng, F, N)
+    llr = np.where(y == 1, -2.6, 2.6).astype(np.float32)
+    ref = O.decode(og, llr, "NMS", 0.75, 30, "flooding", True, depth, n_threads=8)
+    dec = q.Decoder(code, N, 30, rule="NMS", rule_param=0.75, n_frames=F, syndrome_depth=depth, compact="on")
+    hard, it, ok = run(q, torch, dec, llr=llr)
+    assert dec.last_run_stats()["compactions"] >= 2
+    assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()

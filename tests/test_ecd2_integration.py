@@ -220,7 +220,7 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
 def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
     """SURVEY.md 8f #4 second half / VERDICT r1 #4a, #8: two 60 001-bit epochs are loaded as ONE block of 120 002 bits (the LDPC build
     raises MAX_BITS_PER_PROCESSBLOCK, processblock_mgmt.c:94-95; cascade with its unsigned short indices could not take it), at
-    QBER 4.5 % the rate-0.5 plan discloses ~ 50 000 parity bits; `-L p3000` makes every parity packet at most 3 000 bytes so the
+    QBER 4.5 % the plan discloses 42 000 - 50 000 parity bits; `-L p3000` makes every parity packet at most 3 000 bytes so the
     payload travels in several fragments, which Bob reassembles before decoding.  Identical final keys on both sides.  (At 6 % the
     daemon's privacy amplification leaves no key at all when the sampled error rate comes out high: seen once in ten runs.)"""
     binary = need("ecd2_ldpc")
@@ -229,7 +229,7 @@ def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     import re
     m = re.search(r"sent parity in (\d+) packet\(s\), (\d+) key bits", out["a_log"])
-    assert m and int(m.group(1)) >= 3 and int(m.group(2)) > 100000, out["a_log"][-2000:]
+    assert m and int(m.group(1)) >= 2 and int(m.group(2)) > 100000, out["a_log"][-2000:]      # 42 000 .. 50 000 disclosed bits at <= 3 000 bytes a packet
     assert "decoded" in out["b_log"]
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 10000
     assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
