@@ -11,7 +11,7 @@
  *                 second-min / xor do not depend on association order), results go back through LDS
  *                 and are scattered with all lanes busy.  The syndrome of the previous posterior is
  *                 folded in the same pass (one extra bit per edge).
- *   variable nodes: a workgroup owns 256 consecutive VNs = one contiguous slot range, staged through
+ *   variable nodes: a workgroup owns QE_THREADS consecutive VNs = one contiguous slot range, staged through
  *                 LDS so global traffic is coalesced; each lane sums its VN's slots in order (the same
  *                 order as AFF3CT's _initialize_var_to_chk) and the hard decisions leave as wave
  *                 ballots, i.e. directly as MSB-first packed words (helpers.h:65-70).
@@ -26,9 +26,12 @@
 
 #include "qldpc_kernels.h"
 
-#define QE_THREADS 256
+#ifndef QE_THREADS
+#define QE_THREADS 512               /* threads per workgroup = VNs per variable-node chunk (measured per block, with 32 checks per check chunk:
+                                     128: 340 us, 256: 302 us, 512: 284 us, 1024: 313 us) */
+#endif
 #ifndef QE_CPB
-#define QE_CPB 32                 /* checks per workgroup (measured per 65 536-VN block: 64: 335 us, 32: 302 us, 16: 306 us) */
+#define QE_CPB 32                 /* checks per workgroup (measured per 65 536-VN block at 256 threads: 64: 335 us, 32: 302 us, 16: 306 us) */
 #endif
 #define QE_MAX_EDGES (QE_CPB * 64)
 
