@@ -96,7 +96,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->cn_buckets) (void)hipFree(b.d_list);
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
-    (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t);
+    (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t); (void)hipFree(d->d_vn_tr);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
@@ -149,6 +149,12 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     HIPCHK(hipMemcpy(d->d_cn_tr, code->transpose, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_cn_var, code->cn_var, sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->d_vn_ptr, code->vn_ptr, sizeof(int) * ((size_t)d->N + 1), hipMemcpyHostToDevice));
+    {   /* chk_to_var of the frames engine is CN-major: the variable-node passes find the row of slot s at vn_tr[s] */
+        std::vector<int> vt((size_t)d->E + QK_IDX_PAD, 0);
+        for (int k = 0; k < d->E; k++) vt[(size_t)code->transpose[k]] = k;
+        if ((rc = dev_alloc(d, &d->d_vn_tr, vt.size()))) return rc;
+        HIPCHK(hipMemcpy(d->d_vn_tr, vt.data(), sizeof(int) * vt.size(), hipMemcpyHostToDevice));
+    }
     {   /* check -> VN table transposed to [edge position][check] for the syndrome pass (qk_syndrome) */
         d->max_dc = code->max_dc;
         std::vector<int> t((size_t)std::max(1, code->max_dc) * d->M, -1);

@@ -55,6 +55,7 @@ struct qldpc_decoder {
     hipStream_t stream;
     /* graph on device */
     int *d_cn_ptr, *d_cn_tr, *d_cn_var, *d_vn_ptr, *d_info_pos;
+    int *d_vn_tr;                    /* VN-major slot -> CN-major edge (inverse of cn_tr, padded): where chk_to_var of a slot lives */
     int *d_cn_var_t, max_dc;         /* cn_var transposed to [edge position][check], -1 padded (syndrome pass) */
     std::vector<bucket> cn_buckets, vn_buckets;
     std::vector<std::vector<bucket>> layer_buckets;   /* per layer */

@@ -4,7 +4,9 @@
  * Layout ("frame-interleaved"): frames are packed V per wavefront lane, FG = 64*V frames per group.
  *   llr  [G][N][FG] f32      channel LLRs
  *   v2c  [G][E][FG] f32      variable->check messages, VN-major slot order
- *   c2v  [G][E][FG] f32      check->variable messages, VN-major slot order
+ *   c2v  [G][E][FG] f32      check->variable messages, CN-major edge order (every pass WRITES contiguous rows and gathers its reads:
+ *                            measured +4.5 % on the check pass against scattering into VN-major slots; gathered 256-byte row
+ *                            reads run at the rate of streamed ones, tools/tform_bench.hip form D)
  *   sgn / hard [G][N][V] u64 per-VN ballots over the 64 lanes (bit = lane), one per frame-in-lane
  * One wavefront works on ONE graph node for FG frames at a time, so every graph index is
  * wave-uniform (scalar loads) and every message access is a contiguous FG*4-byte row.  The
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                     float o[V];
 #pragma unroll
                     for (int j = 0; j < V; j++) o[j] = acc[j].out(x[k][j], rule);
-                    qk_stm<V>(cout + (size_t)slot[k] * FG, o);
+                    qk_stm<V>(cout + (size_t)(b + k) * FG, o);      /* chk_to_var is CN-major: a check's rows are contiguous */
                 }
         } else {
 #pragma unroll
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
                 if (k < deg) {
 #pragma unroll
                     for (int j = 0; j < V; j++)
-                        if (!frozen[j]) qk_put(&cout[(size_t)slot[k] * FG + j], acc[j].out(x[k][j], rule));
+                        if (!frozen[j]) qk_put(&cout[(size_t)(b + k) * FG + j], acc[j].out(x[k][j], rule));
                 }
         }
     } else {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_flood(const MT *__restrict__
             } else qk_load<V>(x, vin + off);
 #pragma unroll
             for (int j = 0; j < V; j++) o[j] = acc[j].out(qk_prep<FAM>(x[j]), rule);
-            qk_store_masked<V>(cout + off, o, frozen, any_frozen);
+            qk_store_masked<V>(cout + (size_t)(b + k) * FG, o, frozen, any_frozen);
         }
     }
 }
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride,
-                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, int want_ballots = 1)
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, int want_ballots = 1,
+                                                          const int *__restrict__ vn_tr = nullptr)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -555,12 +558,19 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             for (int k = 0; k < dd[u]; k++) qk_stm<V>(vout + (size_t)(bb[u] + k) * FG, o);
         }
     } else if constexpr (DVMAX > 0) {
+        /* chk_to_var is CN-major (the check pass streams it out): slot s of this VN-major order is row vn_tr[s] (padded array) */
+        int tr[UN][DVMAX];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++) tr[u][k] = vn_tr[bb[u] + k];
+        }
         float m[UN][DVMAX][V];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
 #pragma unroll
             for (int k = 0; k < DVMAX; k++)
-                if (k < dd[u]) qk_ldm<V>(m[u][k], cin + (size_t)(bb[u] + k) * FG);
+                if (k < dd[u]) qk_ldm<V>(m[u][k], cin + (size_t)tr[u][k] * FG);
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             for (int j = 0; j < V; j++) sum[j] = 0.0f;
             for (int k = 0; k < dd[u]; k++) {
                 float m[V];
-                qk_load<V>(m, cin + (size_t)(bb[u] + k) * FG);
+                qk_load<V>(m, cin + (size_t)vn_tr[bb[u] + k] * FG);
 #pragma unroll
                 for (int j = 0; j < V; j++) sum[j] += m[j];
             }
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             if constexpr (MODE == QK_VN_NORMAL) {
                 for (int k = 0; k < dd[u]; k++) {
                     float m[V], o[V];
-                    qk_load<V>(m, cin + (size_t)(bb[u] + k) * FG);
+                    qk_load<V>(m, cin + (size_t)vn_tr[bb[u] + k] * FG);
 #pragma unroll
                     for (int j = 0; j < V; j++) o[j] = tmp[u][j] - m[j];
                     qk_stm<V>(vout + (size_t)(bb[u] + k) * FG, o);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(QK_THREADS) void qh_cn_flood(const uint32_t *__rest
             const qi_u2 a = __builtin_bit_cast(qi_u2, x[k] & 0x7fff7fffu);
             const qi_u2 ind = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m2, a), one);      /* 1 iff a < min2, i.e. a == min1 < min2 */
             const uint32_t mag = __builtin_bit_cast(uint32_t, (qi_u2)(n1 + (qi_u2)(ind * dn)));
-            qi_stm(cout + (size_t)slot[k] * 64, mag | ((sg ^ x[k]) & 0x80008000u));
+            qi_stm(cout + (size_t)(b + k) * 64, mag | ((sg ^ x[k]) & 0x80008000u));      /* chk_to_var is CN-major */
         }
 }
 

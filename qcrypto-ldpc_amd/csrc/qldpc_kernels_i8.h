@@ -181,7 +181,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
         lo.finish(rule); hi.finish(rule);
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
-            if (k < deg) qi_stm(cout + (size_t)slot[k] * 64, qi_pack(lo.out(xl[k]), hi.out(xh[k])));
+            if (k < deg) qi_stm(cout + (size_t)(b + k) * 64, qi_pack(lo.out(xl[k]), hi.out(xh[k])));      /* chk_to_var is CN-major */
     } else {
         for (int k = 0; k < deg; k++) {
             qi_s2 xl, xh;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_cn_flood(const uint32_t *__rest
             const size_t off = (size_t)cn_tr[b + k] * 64;
             qi_s2 xl, xh;
             qi_unpack(FIRST ? llr8[((size_t)g * N + cn_var[b + k]) * 64 + lane] : (REMAP ? remap_word((size_t)cn_tr[b + k]) : vin[off]), xl, xh);
-            cout[off] = qi_pack(lo.out(xl), hi.out(xh));
+            cout[(size_t)(b + k) * 64] = qi_pack(lo.out(xl), hi.out(xh));
         }
     }
 }
@@ -213,7 +213,8 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
                                                           float *__restrict__ post_out,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ vn_ptr, int N, size_t group_stride /* dwords */,
-                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f, int want_ballots = 1)
+                                                          const u64 *__restrict__ done, qk_coded_llr coded = qk_coded_llr{}, float scale = 0.0f, int want_ballots = 1,
+                                                          const int *__restrict__ vn_tr = nullptr)
 {
     const int g = blockIdx.y;
     if ((MODE != QK_VN_POST || (want_ballots & 2)) && qk_group_done<QI_V>(done, g)) return;      /* bit 1: see qk_vn_flood */
@@ -265,12 +266,18 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             for (int k = 0; k < dd[u]; k++) qi_stm(vout + (size_t)(bb[u] + k) * 64, y[u]);     /* |Yq| <= 127 already */
         }
     } else if constexpr (DVMAX > 0) {
+        int tr[UN][DVMAX];      /* chk_to_var is CN-major: slot s is row vn_tr[s] */
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++) tr[u][k] = vn_tr[bb[u] + k];
+        }
         uint32_t m[UN][DVMAX];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
 #pragma unroll
             for (int k = 0; k < DVMAX; k++)
-                if (k < dd[u]) m[u][k] = qi_ldm(cin + (size_t)(bb[u] + k) * 64);
+                if (k < dd[u]) m[u][k] = qi_ldm(cin + (size_t)tr[u][k] * 64);
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
@@ -291,13 +298,13 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             qi_unpack(y[u], tl[u], th[u]);
             for (int k = 0; k < dd[u]; k++) {
                 qi_s2 ml, mh;
-                qi_unpack(cin[(size_t)(bb[u] + k) * 64], ml, mh);
+                qi_unpack(cin[(size_t)vn_tr[bb[u] + k] * 64], ml, mh);
                 tl[u] += ml; th[u] += mh;
             }
             if constexpr (MODE == QK_VN_NORMAL) {
                 for (int k = 0; k < dd[u]; k++) {
                     qi_s2 ml, mh;
-                    qi_unpack(cin[(size_t)(bb[u] + k) * 64], ml, mh);
+                    qi_unpack(cin[(size_t)vn_tr[bb[u] + k] * 64], ml, mh);
                     qi_stm(vout + (size_t)(bb[u] + k) * 64, qi_pack(qi_clamp127(tl[u] - ml), qi_clamp127(th[u] - mh)));
                 }
             }

@@ -129,11 +129,11 @@ static void launch_vn_k(qldpc_decoder *d, const bucket &b, float *post_out)
     if (d->llr_coded) {
         qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls, d->has_erase ? d->d_ebits : nullptr};
         hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, true>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, (const float *)nullptr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c, want_ballots(d, MODE));
+                           post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, c, want_ballots(d, MODE), d->d_vn_tr);
         return;
     }
     hipLaunchKernelGGL((qk_vn_flood<V, CAP, UNX, MODE, MT, false>), grid, dim3(QK_THREADS), 0, d->stream, (const MT *)d->d_b, d->d_llr, (MT *)d->d_a, d->d_sgn, d->d_hard,
-                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{}, want_ballots(d, MODE));
+                       post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * d->FG, d->d_done, qk_coded_llr{}, want_ballots(d, MODE), d->d_vn_tr);
 }
 template <int V, int CAP, int MODE>
 static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
@@ -145,10 +145,10 @@ static void launch_vn_one(qldpc_decoder *d, const bucket &b, float *post_out)
             if (d->llr_coded) {
                 qk_coded_llr c{d->d_ybits, d->d_fmag, d->d_fnch, d->d_vcls, d->has_erase ? d->d_ebits : nullptr};
                 hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, true>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, (const uint32_t *)nullptr, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale, want_ballots(d, MODE));
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, c, d->quant_scale, want_ballots(d, MODE), d->d_vn_tr);
             } else
                 hipLaunchKernelGGL((qi_vn_flood<CAP, UN, MODE, false>), grid, dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_b, d->d_llr8, (uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr,
-                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f, want_ballots(d, MODE));
+                                   post_out, b.d_list, b.n, d->d_vn_ptr, d->N, (size_t)d->E * 64, d->d_done, qk_coded_llr{}, 0.0f, want_ballots(d, MODE), d->d_vn_tr);
         }
         return;
     }

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void d_cn(const float* __restrict__ v2c, float
 #pragma unroll
     for (int k = 0; k < DC; k++) stnt(out + (size_t)k * 64, o[k]);
 }
-template <int DVMAX, int UN>
+template <int DVMAX, int UN, bool GATHER = true, bool LLR = true>
 __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const float* __restrict__ llr, float* __restrict__ v2c, const int* __restrict__ vptr,
                                             const int* __restrict__ cnslot, int N, size_t E, int v_lo, int v_hi)
 {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const
 #pragma unroll
     for (int u = 0; u < UN; u++) {
 #pragma unroll
-        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];
+        for (int k = 0; k < DVMAX; k++) e[u][k] = GATHER ? cnslot[s0[u] + k] : s0[u] + k;
     }
     float m[UN][DVMAX];
 #pragma unroll
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < DVMAX; k++) if (k < d[u]) sum += m[u][k];
-        const float t = ldnt(llr + ((size_t)g * N + vv[u]) * 64 + lane) + sum;
+        const float t = (LLR ? ldnt(llr + ((size_t)g * N + vv[u]) * 64 + lane) : (float)(vv[u] & 7)) + sum;
         float* out = v2c + ((size_t)g * E + s0[u]) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < DVMAX; k++) if (k < d[u]) stnt(out + (size_t)k * 64, t - m[u][k]);
@@ -513,6 +513,14 @@ int main(int argc, char** argv)
             d_vn<12, 2><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
             d_vn<4, 4><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
         printf("iteration: D %.3f ms (%.1f %% vs A %.3f ms)\n", dcn + dvn, 100.0 * (dcn + dvn) / (acn + avn) - 100.0, acn + avn);
+        // the engine's VN pass rebuilds the channel LLR from ballots (no LLR row read) and takes 2 - 4 VNs per wavefront: the same kernel shape, with and without the gather
+        float avn2 = timeit("A' vn stream c2v, stream v2c, no LLR rows (2E)", 2.0 * E, [&] {
+            d_vn<12, 2, false, false><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+            d_vn<4, 4, false, false><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
+        float dvn2 = timeit("D' vn gather c2v, stream v2c, no LLR rows (2E)", 2.0 * E, [&] {
+            d_vn<12, 2, true, false><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+            d_vn<4, 4, true, false><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
+        printf("iteration: A' %.3f ms   D' %.3f ms (%.1f %%)\n", acn + avn2, dcn + dvn2, 100.0 * (dcn + dvn2) / (acn + avn2) - 100.0);
     }
     printf("iteration: B' %.3f ms (%.1f %%)\n", b2cn + b2vn, 100.0 * (b2cn + b2vn) / (acn + avn) - 100.0);
     printf("iteration: A %.3f ms   B %.3f ms (%.1f %%)   B(nt) %.3f ms (%.1f %%)\n", acn + avn, bcn + bvn, 100.0 * (bcn + bvn) / (acn + avn) - 100.0,
