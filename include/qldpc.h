@@ -341,6 +341,7 @@ void qldpc_recon_free(qldpc_recon *r);
 int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon_msg *msg);
 int qldpc_recon_parity_words(const qldpc_recon_msg *msg);    /* words of disclosed parity a message carries: ceil((code_m - n_punct)/32) */
 int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg);     /* code_m - n_punct + 32 (CRC)                                             */
+int qldpc_recon_check_header(const qldpc_recon *r, const qldpc_recon_msg *msg, int key_bits);      /* QLDPC_OK / QLDPC_ESIZE: as the decode calls check it */
 long qldpc_recon_entries_created(const qldpc_recon *r);      /* (code, encoder, decoder) sets built so far: constant after a preload   */
 /* qldpc_profile_enable / _read of Bob's decoders, summed over the session's codes by kernel kind */
 int qldpc_recon_profile_enable(qldpc_recon *r, int on);

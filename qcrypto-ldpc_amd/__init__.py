@@ -531,6 +531,7 @@ _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
 _sig("qldpc_recon_parity_words", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_leaked_bits", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_entries_created", C.c_long, [_vp])
+_sig("qldpc_recon_check_header", C.c_int, [_vp, C.POINTER(ReconMsg), C.c_int])
 _sig("qldpc_recon_profile_enable", C.c_int, [_vp, C.c_int])
 _sig("qldpc_recon_profile_read", C.c_int, [_vp, C.POINTER(KernelStat), C.c_int])
 

@@ -395,6 +395,14 @@ static int check_msg(const qldpc_recon *r, const qldpc_recon_msg *m, int key_bit
     return QLDPC_OK;
 }
 
+/* QLDPC_OK if the header is what this side's plan gives for its rate index and the block's length (what the decode calls check per
+ * message): lets a packet handler refuse a header before it allocates for its payload */
+extern "C" int qldpc_recon_check_header(const qldpc_recon *r, const qldpc_recon_msg *msg, int key_bits)
+{
+    if (!r || !msg) return QLDPC_EINVAL;
+    return check_msg(r, msg, key_bits);
+}
+
 /* blocks of ONE entry (same K, M): one encoder launch.  parity[i] receives ceil((M - n_punct) / 32) words. */
 static int encode_group(qldpc_recon *r, int n, const uint32_t *const *key, const int *key_bits, qldpc_recon_msg *const *msgs, uint32_t *const *parity)
 {

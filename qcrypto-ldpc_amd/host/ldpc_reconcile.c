@@ -24,7 +24,7 @@ static qldpc_recon *g_recon = NULL;
 static int ldpc_batchSize(void);
 
 /* ---- options: the daemon's -L letter (ecd2.c:26), with the environment as the fall-back for unmodified command lines ---------- */
-static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0;
+static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0;
 static int g_batch = -1, g_wait_ms = -1;
 
 static int ldpc_envInt(const char *name, int dflt)
@@ -49,6 +49,7 @@ int ldpc_parseOption(const char *optarg)
         case 'p': g_opt_max_packet = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_max_packet < 256) return 1; break;
         case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* fault injection (tests): flip n disclosed parity bits */
         case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* fault injection (tests): send every parity packet n more times */
+        case 'y': g_opt_badhdr = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* fault injection (tests): claim another rate index in the header */
         default: return 1;
         }
         p = end;
@@ -296,7 +297,7 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
         const unsigned int off = f * perPacket, words = (parityWords - off < perPacket) ? parityWords - off : perPacket;
         EcPktHdr_LdpcParity *h9;
         if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE, pb))) break;
-        h9->rateIndex = msg.rate_index; h9->keyBits = msg.key_bits; h9->codeK = msg.code_k; h9->codeM = msg.code_m;
+        h9->rateIndex = msg.rate_index + (unsigned int)g_opt_badhdr; h9->keyBits = msg.key_bits; h9->codeK = msg.code_k; h9->codeM = msg.code_m;
         h9->crc32 = msg.crc32; h9->nPunct = msg.n_punct;
         h9->fragIndex = f; h9->fragCount = fragCount; h9->fragWordOffset = off;
         memcpy(&h9[1], parity + off, words * WORD_SIZE);
@@ -325,6 +326,8 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
 
 /* ---- EC follower ("Bob"): decode, verify, verdict, privacy amplification --------------------- */
 
+static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int decoded, int corrected, int iterations);
+
 /* one fragment of a block's parity: validate it against the block and against the fragments seen so far, copy its words.
  * returns 0 and *complete = 1 once every fragment is there; a packet for a block that is not waiting for parity (a duplicate after
  * completion, a packet for the wrong role) is ignored (*complete = 0). */
@@ -344,6 +347,18 @@ static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *co
     if (in->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
     if (in->fragWordOffset > totalWords || words > totalWords - in->fragWordOffset) return LDPC_ERR_PKT_SIZE;
     if (!ld->parityWords) {
+        qldpc_recon_msg first;
+        memset(&first, 0, sizeof(first));
+        first.rate_index = in->rateIndex; first.key_bits = in->keyBits; first.code_k = in->codeK; first.code_m = in->codeM;
+        first.crc32 = in->crc32; first.n_punct = in->nPunct;
+        /* the dimensions must be what THIS side's rate table gives for the block before anything is allocated for the payload */
+        if (qldpc_recon_check_header(g_recon, &first, pb->workbits) != QLDPC_OK) {
+            /* answer it (the initiator waits for a verdict): failed, i.e. both sides fall back to cascade; what the packet says was disclosed
+             * is charged to the leakage account */
+            printf("ldpc: epoch %08x: parity header refused (%s)\n", pb->startEpoch, qldpc_last_error());
+            ld->parityState = 1;
+            return ldpc_finishBlock(pb, &first, 0, 0, 0);
+        }
         ld->parityWords = (unsigned int *)malloc2(totalWords * WORD_SIZE + WORD_SIZE);
         if (!ld->parityWords) return 43;
         memset(ld->parityWords, 0, totalWords * WORD_SIZE + WORD_SIZE);

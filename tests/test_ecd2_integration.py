@@ -253,3 +253,17 @@ def test_sample_without_errors_and_repeated_parity_packets(tmp_path):
     assert dup["a_final"] is not None and dup["b_final"] is not None, dup["a_log"][-2000:] + "\n----\n" + dup["b_log"][-2000:]
     assert (dup["a_final"]["words"] == dup["b_final"]["words"]).all()
     assert dup["b_log"].count("decoded 1") + dup["b_log"].count(": decoded ") >= 1 and "Segmentation" not in dup["b_log"]
+
+
+@pytest.mark.gpu
+def test_refused_parity_header_gets_a_failed_verdict_and_the_block_falls_back(tmp_path):
+    """a parity header that is not what the follower's own rate table gives for the block (`-L y1`: Alice claims the next
+    rate index with the dimensions of the real one) is refused BEFORE anything is allocated for its payload, answered with a failed
+    verdict -- the initiator is not left waiting -- and the block is reconciled by cascade in the same daemons."""
+    binary = need("ecd2_ldpc")
+    a, b = epochs(31, 4, 5003, 0.02)
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,y1"], timeout=90)
+    assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
+    assert "parity header refused" in out["b_log"] and "falling back to cascade as EC follower" in out["b_log"]
+    assert "falling back to cascade as EC initiator" in out["a_log"]
+    assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
