@@ -29,3 +29,24 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_oracle_on_sample"] is True
     assert d["value"] > 0 and d["fer"] < 0.5
     assert d["int8_messages"]["fixed"]["value"] > 0 and d["fp16_messages"]["fixed"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one():
+    """one default run puts BASELINE configs 2 (the line itself), 3 and 5 in front of the driver, each with its own roofline,
+    moved bytes beside algorithmic bytes, and no fraction above 1 (round 1's layered mode summed one pass three times)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 4096
+    r = d["roofline"]
+    assert r["traffic"] is not None and 0.95 < r["traffic"] / r["alg_bytes_per_launch"] < 1.1      # PMC traffic of the check pass ~ its algorithmic bytes
+    fracs = [r["frac"], r["vn_update"]["frac"], r["vn_update"]["moved_frac"], r["whole_step"]["frac"], r["whole_step"]["moved_frac"]]
+    assert r["vn_update"]["moved_bytes_per_pass"] < r["vn_update"]["alg_bytes_per_pass"]              # coded LLRs: fewer bytes than SURVEY 8d prices
+    e = d["early_exit"]
+    assert e["compactions"] >= 1 and 0.9 < e["useful_work"] <= 1.0 and e["value"] > 2.5 * d["value"]
+    c3, c5 = d["config3_multirate_stream"], d["config5_layered_1e6"]
+    assert c3["value"] > 0 and c3["fer"] <= 0.01 and 0.25 < c3["leaked_fraction"] < 0.33 and sum(c3["epochs_per_rate"].values()) == 512
+    assert c5["early_exit"]["value"] > c5["fixed"]["value"] > 0 and c5["early_exit"]["avg_sweeps"] < 10 and c5["fixed"]["fer"] == 0.0
+    fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["frac"], c5["early_exit"]["roofline"]["frac"]]
+    assert all(0.0 < f <= 1.0 for f in fracs), fracs
