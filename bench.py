@@ -289,8 +289,8 @@ def main():
     int8 = variant("i8") if (not args.no_int8 and args.rule in ("MS", "OMS", "NMS")) else None
 
     # ---- BASELINE config 5: N = 10^6 irregular LDPC, horizontal-layered schedule, per-sweep syndrome early termination ----------
-    def config5():
-        n5, k5, f5 = 1000000, 800000, 64
+    def config5(f5=64):
+        n5, k5 = 1000000, 800000
         code5 = q.Code.ira(n5, k5, 0.125, 11, 3, 7)
         enc5 = q.Encoder(code5, "IRA", device=local_rank)
         cw5, rx5 = make_frames(q, torch, code5, enc5, f5, args.qber, 5000, device)
@@ -337,7 +337,7 @@ def main():
     # ---- BASELINE config 3: multi-rate H set {0.5, 0.7, 0.8, 0.9} chosen per epoch from the estimated QBER, a stream of epochs through
     #      the reconciliation sessions (what the ecd2 handlers call), HOST buffers in and out ----------------------------------------
     def config3():
-        epochs_n, key_bits, batch = 512, 52429, 64
+        epochs_n, key_bits, batch = 512, 52429, 256      # the daemon's batched ingest (-L b<n>); 64: 0.73, 128: 0.87, 256: 0.99 Gbit/s
         rng = np.random.default_rng(42)
         qbers = rng.uniform(0.005, 0.06, epochs_n).astype(np.float32)
         alice = rng.integers(0, 2, (epochs_n, key_bits)).astype(np.uint8)
@@ -389,7 +389,10 @@ def main():
     cfg3 = cfg5 = None
     if rank == 0 and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32" and (N, K) == (65536, 52429):
         if not args.no_config5:
-            cfg5 = config5()
+            cfg5 = config5()                    # batch 64 (one frame group: 6 667 waves per colour layer)
+            big = config5(256)                  # the same code with enough frames to fill the chip
+            cfg5["at_256_frames"] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"]}
+                                     for k_ in ("fixed", "early_exit")}
         if not args.no_config3:
             cfg3 = config3()
 

@@ -271,7 +271,9 @@ int qldpc_last_run_iterations(const qldpc_decoder *dec);
 int qldpc_last_run_stats(qldpc_decoder *dec, long long out[4]);
 
 /* ------------------------------------------------------------------ encoder (Alice) ---------- */
-/* method: "IRA" (dual-diagonal accumulate) or "IDENTITY" (GF(2) elimination, any full-rank H). */
+/* method: "IRA" (dual-diagonal accumulate), "IDENTITY" / "LU_DEC" (Encoder_LDPC_from_H's two G_methods, VAR/main.cpp (alist-v1.0.1):135-145:
+ * GF(2) elimination of any H, parity positions searched from the first / from the last column) or "QC" (Encoder_LDPC_from_QC,
+ * VAR/main.cpp (qc):145: info bits first, parity = H2^-1 H1 u; QLDPC_EUNSUPPORTED when H2 is singular). */
 int qldpc_encoder_create(const qldpc_code *code, const char *method, int device, qldpc_encoder **out);
 void qldpc_encoder_free(qldpc_encoder *enc);
 int qldpc_encoder_k(const qldpc_encoder *enc);

@@ -444,7 +444,7 @@ class Decoder:
 
 
 class Encoder:
-    """m.encoder->encode (BS/src/main.cpp:341): method 'IRA' or 'IDENTITY' (Encoder_LDPC_from_H)."""
+    """m.encoder->encode (BS/src/main.cpp:341): method 'IRA', 'IDENTITY' / 'LU_DEC' (Encoder_LDPC_from_H's G_methods) or 'QC' (Encoder_LDPC_from_QC)."""
 
     def __init__(self, code, method="IDENTITY", device=0):
         h = _vp()

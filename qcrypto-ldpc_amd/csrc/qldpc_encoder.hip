@@ -6,6 +6,11 @@
  *              accumulator, p_0 = s_0, p_c = p_{c-1} ^ s_c with s = H_info u.
  *   "IDENTITY" Encoder_LDPC_from_H(K, N, H, "IDENTITY", ...) (VAR/main.cpp (alist-v1.0.1):142-145):
  *              systematic form by GF(2) elimination, parity = A u; get_info_bits_pos() (:147-159).
+ *   "LU_DEC"   the harness' other G_method (:135): the same elimination with the pivots searched from the last column down, so the
+ *              parity bits sit at the end of the codeword wherever H allows.  AFF3CT's own column permutation has no vector in the
+ *              reference (parity unpinned): take the positions from qldpc_encoder_info_bits_pos, as the harness does (:147-159).
+ *   "QC"       Encoder_LDPC_from_QC (VAR/main.cpp (qc):145): x = [u | H2^-1 H1 u], info bits = the first N - M positions;
+ *              refused when the last M columns of H are singular (AFF3CT throws there too).
  * Bits are packed MSB-first in 32-bit words like ProcessBlock.mainBufPtr (helpers.h:65-70).
  */
 #include <hip/hip_runtime.h>
@@ -122,9 +127,9 @@ static int enc_create(const qldpc_code *code, const char *method, int device, ql
         HIPCHK(hipMalloc((void **)&e->d_cn_var, sizeof(int) * (size_t)code->E));
         HIPCHK(hipMemcpy(e->d_cn_ptr, code->cn_ptr, sizeof(int) * ((size_t)e->M + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_cn_var, code->cn_var, sizeof(int) * (size_t)code->E, hipMemcpyHostToDevice));
-    } else if (!strcmp(method, "IDENTITY")) {
+    } else if (!strcmp(method, "IDENTITY") || !strcmp(method, "LU_DEC") || !strcmp(method, "QC")) {
         int *piv = nullptr, *fr = nullptr; uint64_t *A = nullptr; int wpr64 = 0;
-        const int r = qldpc_gf2_systematic(code, &piv, &fr, &A, &wpr64);
+        const int r = qldpc_gf2_systematic_ord(code, method[0] == 'I' ? 0 : method[0] == 'L' ? 1 : 2, &piv, &fr, &A, &wpr64);
         if (r < 0) return r;
         e->ira = 0; e->R = r; e->K = e->N - r; e->wpr = (e->K + 31) / 32;
         for (int j = 0; j < r; j++) { e->parity_pos.push_back(piv[j]); map[(size_t)piv[j]] = -1 - j; }
@@ -137,7 +142,7 @@ static int enc_create(const qldpc_code *code, const char *method, int device, ql
         HIPCHK(hipMalloc((void **)&e->d_A, sizeof(uint32_t) * A32.size()));
         HIPCHK(hipMemcpy(e->d_A, A32.data(), sizeof(uint32_t) * A32.size(), hipMemcpyHostToDevice));
     } else {
-        qldpc_set_error("encoder: unknown method '%s' (IRA | IDENTITY)", method);
+        qldpc_set_error("encoder: unknown method '%s' (IRA | IDENTITY | LU_DEC | QC)", method);
         return QLDPC_EINVAL;
     }
     HIPCHK(hipMalloc((void **)&e->d_map, sizeof(int) * (size_t)e->N));

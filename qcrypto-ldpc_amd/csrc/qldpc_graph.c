@@ -463,6 +463,19 @@ int qldpc_code_syndrome_host(const qldpc_code *c, const int *x, int *s)
  */
 int qldpc_gf2_systematic(const qldpc_code *g, int **pivots_out, int **free_out, uint64_t **A_out, int *wpr_out)
 {
+    return qldpc_gf2_systematic_ord(g, 0, pivots_out, free_out, A_out, wpr_out);
+}
+
+/*
+ * The same elimination with the pivot search in another column order:
+ *   order 0  ascending  ("IDENTITY": the KAT's info_bits_pos = 504..1007 comes out of this one)
+ *   order 1  descending ("LU_DEC" of Encoder_LDPC_from_H, VAR/main.cpp (alist-v1.0.1):135-145: parity at the END of the codeword where H allows)
+ *   order 2  the last M columns only ("QC" = Encoder_LDPC_from_QC, VAR/main.cpp (qc):145: x = [u | H2^-1 H1 u]; H2 singular is an error there too)
+ * Pivots come back sorted by column so that parity index j means the same thing for every order.
+ */
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int qldpc_gf2_systematic_ord(const qldpc_code *g, int order, int **pivots_out, int **free_out, uint64_t **A_out, int *wpr_out)
+{
     const int N = g->N, M = g->M;
     const size_t W = ((size_t)N + 63) / 64;
     if ((double)M * (double)W * 8.0 > 2.0e9) { qldpc_set_error("IDENTITY encoder: H too large for dense elimination (%d x %d)", M, N); return QLDPC_EUNSUPPORTED; }
@@ -471,15 +484,33 @@ int qldpc_gf2_systematic(const qldpc_code *g, int **pivots_out, int **free_out, 
     if (!R || !piv) { free(R); free(piv); return QLDPC_ENOMEM; }
     for (int m = 0; m < M; m++) for (int k = g->cn_ptr[m]; k < g->cn_ptr[m + 1]; k++) R[(size_t)m * W + g->cn_var[k] / 64] ^= 1ull << (g->cn_var[k] % 64);
     int r = 0;
-    for (int col = 0; col < N && r < M; col++) {
+    if (order < 0 || order > 2) { free(R); free(piv); return QLDPC_EINVAL; }
+    for (int step = 0; step < N && r < M; step++) {
+        const int col = order == 0 ? step : N - 1 - step;
+        if (order == 2 && col < N - M) break;
         int p = -1;
         for (int m = r; m < M; m++) if (R[(size_t)m * W + col / 64] >> (col % 64) & 1) { p = m; break; }
         if (p < 0) continue;
         if (p != r) for (size_t w = 0; w < W; w++) { uint64_t t = R[(size_t)p * W + w]; R[(size_t)p * W + w] = R[(size_t)r * W + w]; R[(size_t)r * W + w] = t; }
         for (int m = 0; m < M; m++)
             if (m != r && (R[(size_t)m * W + col / 64] >> (col % 64) & 1))
-                for (size_t w = col / 64; w < W; w++) R[(size_t)m * W + w] ^= R[(size_t)r * W + w];
+                for (size_t w = order == 0 ? (size_t)col / 64 : 0; w < W; w++) R[(size_t)m * W + w] ^= R[(size_t)r * W + w];
         piv[r++] = col;
+    }
+    if (order == 2 && r < M) {
+        free(R); free(piv);
+        qldpc_set_error("QC encoder: the last %d columns of H (H2) are not invertible (rank %d)", M, r);
+        return QLDPC_EUNSUPPORTED;
+    }
+    if (order != 0) {      /* row j of the reduced matrix belongs to pivot piv[j]: sort both by column */
+        int *ord = (int *)malloc(sizeof(int) * 2 * (size_t)(r > 0 ? r : 1));
+        uint64_t *R2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(r > 0 ? r : 1) * W);
+        if (!ord || !R2) { free(ord); free(R2); free(R); free(piv); return QLDPC_ENOMEM; }
+        for (int j = 0; j < r; j++) { ord[2 * j] = piv[j]; ord[2 * j + 1] = j; }
+        qsort(ord, (size_t)r, 2 * sizeof(int), cmp_int);
+        for (int j = 0; j < r; j++) { memcpy(R2 + (size_t)j * W, R + (size_t)ord[2 * j + 1] * W, sizeof(uint64_t) * W); piv[j] = ord[2 * j]; }
+        memcpy(R, R2, sizeof(uint64_t) * (size_t)r * W);
+        free(ord); free(R2);
     }
     const int K = N - r;
     int *fr = (int *)malloc(sizeof(int) * (size_t)(K > 0 ? K : 1));

@@ -35,6 +35,7 @@ void qldpc_set_error(const char *fmt, ...);
 /* GF(2) systematic form: returns rank r; pivots[r] parity positions (ascending pivot search),
  * free_pos[N-r] info positions, A[r][ceil((N-r)/64)] bit rows with x_pivot[j] = <A[j], x_free>. */
 int qldpc_gf2_systematic(const struct qldpc_code *code, int **pivots, int **free_pos, uint64_t **A, int *words_per_row);
+int qldpc_gf2_systematic_ord(const struct qldpc_code *code, int order, int **pivots, int **free_pos, uint64_t **A, int *words_per_row);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
  */
 #include "ldpc_reconcile.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,7 +25,7 @@ static qldpc_recon *g_recon = NULL;
 static int ldpc_batchSize(void);
 
 /* ---- options: the daemon's -L letter (ecd2.c:26), with the environment as the fall-back for unmodified command lines ---------- */
-static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0;
+static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_margin = 0;
 static int g_batch = -1, g_wait_ms = -1;
 
 static int ldpc_envInt(const char *name, int dflt)
@@ -49,6 +50,7 @@ int ldpc_parseOption(const char *optarg)
         case 'p': g_opt_max_packet = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_max_packet < 256) return 1; break;
         case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* fault injection (tests): flip n disclosed parity bits */
         case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* fault injection (tests): send every parity packet n more times */
+        case 'm': g_opt_margin = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_margin < 0 || g_opt_margin > 100) return 1; break;   /* plan for qber + n/10 sigma of its estimate */
         case 'y': g_opt_badhdr = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* fault injection (tests): claim another rate index in the header */
         default: return 1;
         }
@@ -57,6 +59,18 @@ int ldpc_parseOption(const char *optarg)
         else if (*p) return 1;
     }
     return 0;
+}
+
+/* The error rate the initiator plans the code for.  localError comes from a sample of n = initialBits - workbits revealed bits
+ * (qber_estim.c:203-238), so on short blocks it is off by a sigma = sqrt(q (1 - q) / n) that is not small against the distance the
+ * plan keeps from capacity (a 1 000-bit sample at 3 %: +-0.54 %); -L m<n> plans for q + n/10 sigma.  The follower's LLRs keep its own
+ * estimate: only the disclosed amount changes, and it travels in the header. */
+static float ldpc_planQber(const ProcessBlock *pb)
+{
+    const float q = pb->localError;
+    const int n = pb->initialBits - pb->workbits;
+    if (g_opt_margin <= 0 || n <= 0 || !(q > 0.0f)) return q;
+    return q + 0.1f * (float)g_opt_margin * sqrtf(q * (1.0f - q) / (float)n);
 }
 
 int ldpc_selected(void) { return g_opt_select >= 0 ? g_opt_select : (getenv("ECD2_LDPC") != NULL); }
@@ -272,13 +286,13 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
     unsigned int parityWords, perPacket, fragCount, f;
     int rc, errorCode = 0;
 
-    rc = qldpc_recon_plan(g_recon, pb->workbits, pb->localError, &msg);
+    rc = qldpc_recon_plan(g_recon, pb->workbits, ldpc_planQber(pb), &msg);
     if (rc == QLDPC_EUNSUPPORTED) return LDPC_ERR_RATE;
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
     parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
     parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
     if (!parity) return 43;
-    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, pb->localError, &msg, parity, (int)parityWords);
+    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, ldpc_planQber(pb), &msg, parity, (int)parityWords);
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
     {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits */
         const int n = g_opt_fault >= 0 ? g_opt_fault : ldpc_envInt("ECD2_LDPC_FAULT", 0), disclosed = (int)(msg.code_m - msg.n_punct);

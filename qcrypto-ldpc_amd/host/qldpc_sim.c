@@ -12,6 +12,7 @@
  *                  [-i n_ite] [-f frames_per_ber] [-b batch] [-s ber_min:ber_max:ber_step] [-S seed] [-l (layered)] [-n (no syndrome)]
  *                  [-P depth (progressive-edge-growth information part instead of the seeded socket shuffle)]
  *                  [-d parity_ber (dirty disclosed parity bits, BS/data_dvb/data5)]
+ *                  [-G IDENTITY|LU_DEC|QC (encoder construction: p.G_method / Encoder_LDPC_from_QC)]
  *                  [-R (with -e: report every random pattern -- one per batch -- and keep the best; -o file writes its VN indices)]
  *                  [-Q 32|16|8 (message storage: fp32 = the AFF3CT float build, binary16, 8-bit fixed-point min-sum)]
  *                  [-e f (puncture parity bits to reach the rate min_cr(ber, f); random pattern re-drawn per batch, main.cpp:321-333,359-362)]
@@ -59,7 +60,8 @@ int main(int argc, char **argv)
     float param = 0.75f;
     double ber_min = 0.01, ber_max = 0.03, ber_step = 0.005;
     uint64_t seed = 0;
-    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:Q:o:Rln")) != -1) {
+    const char *g_method = NULL;
+    while ((opt = getopt(argc, argv, "N:K:a:q:r:p:i:f:b:s:S:P:e:d:Q:o:G:Rln")) != -1) {
         switch (opt) {
         case 'N': N = atoi(optarg); break;
         case 'K': K = atoi(optarg); break;
@@ -78,6 +80,7 @@ int main(int argc, char **argv)
         case 'Q': msg_bits = atoi(optarg); break;
         case 'R': search = 1; break;
         case 'o': pattern_out = optarg; break;
+        case 'G': g_method = optarg; break;      /* p.G_method (VAR/main.cpp (alist-v1.0.1):135): IDENTITY | LU_DEC; QC = Encoder_LDPC_from_QC ((qc):145) */
         case 'l': layered = 1; break;
         case 'n': synd = 0; break;
         default: fprintf(stderr, "see the header of qldpc_sim.c for usage\n"); return 2;
@@ -93,7 +96,7 @@ int main(int argc, char **argv)
     if (rc) return die("code", rc);
     N = qldpc_code_n(H);
     qldpc_encoder *enc = NULL;
-    if ((rc = qldpc_encoder_create(H, qldpc_code_is_ira(H) ? "IRA" : "IDENTITY", 0, &enc))) return die("encoder", rc);
+    if ((rc = qldpc_encoder_create(H, g_method ? g_method : qldpc_code_is_ira(H) ? "IRA" : "IDENTITY", 0, &enc))) return die("encoder", rc);
     K = qldpc_encoder_k(enc);
     int *pos = (int *)malloc(sizeof(int) * (size_t)K);
     qldpc_encoder_info_bits_pos(enc, pos);

@@ -5,6 +5,7 @@ packets unchanged, remotecrypto/transferd.c:766-768).  Inputs are synthetic stre
 (packetheaders/pkt_header_3.h:4-12: {tag 3, epoch, length in bits, bitsperentry 1} + MSB-first words);
 outputs are the stream-7 final key files of both sides.  Test infrastructure only.
 """
+import errno
 import os
 import struct
 import subprocess
@@ -66,7 +67,18 @@ def run_loopback(binary, workdir, alice_bits, bob_bits, epoch0=0xb0b80000, env_e
         for nb in blocks_:
             starts.append(e)
             e += nb
-        with open(os.path.join(d, "a_cmd"), "w") as f:
+        # a daemon that refused its options never opens its command pipe: a blocking open() here would wait for ever
+        fd, tw = None, time.time()
+        while fd is None:
+            try:
+                fd = os.open(os.path.join(d, "a_cmd"), os.O_WRONLY | os.O_NONBLOCK)
+            except OSError as e:
+                if e.errno != errno.ENXIO or pa.poll() is not None or time.time() - tw > 30:
+                    break
+                time.sleep(0.05)
+        if fd is not None:
+            os.set_blocking(fd, True)
+        with (os.fdopen(fd, "w") if fd is not None else open(os.devnull, "w")) as f:
             # one line per write, spaced out: the daemon parses ONE command per wake-up of its command pipe, so lines that
             # pile up while a handler is busy (the first block pays for GPU start-up and code construction) would be lost
             for i, (st, nb) in enumerate(zip(starts, blocks_)):

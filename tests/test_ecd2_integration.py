@@ -267,3 +267,25 @@ def test_refused_parity_header_gets_a_failed_verdict_and_the_block_falls_back(tm
     assert "parity header refused" in out["b_log"] and "falling back to cascade as EC follower" in out["b_log"]
     assert "falling back to cascade as EC initiator" in out["a_log"]
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
+
+
+@pytest.mark.gpu
+def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
+    """`-L m<n>` on the initiator: the code is planned for q + n/10 sigma of the sampled estimate (short blocks: the estimate is noisy and
+    the plan sits 0.02 - 0.05 from capacity).  More parity bits go out, the header carries the plan, the follower needs no option."""
+    import re
+    binary = need("ecd2_ldpc")
+    a, b = epochs(5, 2, 6001, 0.03)
+    base = run_loopback(binary, tmp_path / "m0", a, b, extra_args=["-L", "1"], timeout=90)
+    marg = run_loopback(binary, tmp_path / "m60", a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,m60"], timeout=90)
+    d = []
+    for out in (base, marg):
+        assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
+        assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
+        d.append(int(re.search(r"(\d+) bits disclosed", out["a_log"]).group(1)))
+    assert d[1] > d[0]      # six sigma of a ~1 000-bit sample at 3 %: about +3 % of QBER (each run draws its own sample: the two estimates differ by ~1.4 sigma)
+    assert marg["a_final"]["nbits"] <= base["a_final"]["nbits"]          # and privacy amplification removes what was disclosed
+    import subprocess
+    args = [binary, "-c", "c", "-s", "s", "-r", "r", "-d", "d", "-f", "f", "-l", "l", "-q", "q", "-Q", "Q"]
+    bad = subprocess.run(args + ["-L", "1,m500"], cwd=str(tmp_path), capture_output=True, text=True, timeout=20)      # out of range: refused while parsing options
+    assert bad.returncode != 0 and "engine ready" not in bad.stdout

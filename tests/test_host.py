@@ -286,3 +286,38 @@ def test_qc_peg_generator(q, O, tmp_path):
     for bad in ((12, 6, 7, 601), (12, 6, 3, 1), (0, 6, 3, 601)):
         with pytest.raises(q.QldpcError):
             q.Code.qc_peg(*bad)
+
+
+@pytest.mark.parametrize("order,name", [(0, "IDENTITY"), (1, "LU_DEC"), (2, "QC")])
+def test_gf2_elimination_orders_give_systematic_generators(q, gold, order, name):
+    """The host half of Encoder_LDPC_from_H's G_methods and Encoder_LDPC_from_QC (VAR/main.cpp (alist-v1.0.1):135-145, (qc):145):
+    whatever the pivot order, x_parity = A x_info satisfies H x = 0 and the positions partition 0..N-1."""
+    import ctypes as C
+    code = q.Code.from_alist(os.path.join(gold, "PEGReg504x1008.alist")) if order < 2 else q.Code.from_qc(os.path.join(gold, "NR_1_0_2.qc"))
+    f = q._L.qldpc_gf2_systematic_ord
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]
+    piv, fr, A, wpr = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_uint64)(), C.c_int()
+    r = f(code._h, order, C.byref(piv), C.byref(fr), C.byref(A), C.byref(wpr))
+    if order == 2 and r < 0:
+        assert b"not invertible" in q._L.qldpc_last_error()
+        return
+    assert r > 0
+    N, K = code.N, code.N - r
+    pv, fp = np.array(piv[:r]), np.array(fr[:K])
+    assert (np.diff(pv) > 0).all() and sorted(pv.tolist() + fp.tolist()) == list(range(N))
+    if order == 0:
+        assert (fp == np.arange(504, 1008)).all()          # the KAT's info_bits_pos (VAR/main.cpp (alist-v1.0.1):445-460)
+    if order == 2:
+        assert (fp == np.arange(K)).all()
+    Ab = np.array(A[:r * wpr.value], dtype=np.uint64).reshape(r, wpr.value)
+    bits = ((Ab[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)).reshape(r, -1)[:, :K].astype(np.uint8)
+    rng = np.random.default_rng(order)
+    u = rng.integers(0, 2, K).astype(np.uint8)
+    x = np.zeros(N, np.uint8)
+    x[fp] = u
+    x[pv] = (bits @ u) & 1
+    assert code.syndrome(x)[0] == 0
+    libc = C.CDLL(None)
+    for p in (piv, fr, A):
+        libc.free(C.cast(p, C.c_void_p))

@@ -214,6 +214,36 @@ def test_encoder_identity_matches_kat(q, peg, kat):
     assert (X[0] == np.array(kat["encoded"])).all()
 
 
+def test_encoder_lu_dec_and_qc_methods(q, peg, kat, gold):
+    """The harness' other encoder constructions (VAR/main.cpp (alist-v1.0.1):135-145 G_method "LU_DEC", (qc):145 Encoder_LDPC_from_QC):
+    systematic codewords with H x = 0 and the information bits where get_info_bits_pos says.  No reference vector exists for either
+    (parity unpinned: AFF3CT's LU_DEC column permutation may differ); the contract the harness relies on is what is checked."""
+    code, _ = peg
+    rng = np.random.default_rng(8)
+    lu = q.Encoder(code, "LU_DEC")
+    assert lu.K == 504 and len(set(lu.info_bits_pos.tolist())) == 504 and (lu.info_bits_pos != q.Encoder(code, "IDENTITY").info_bits_pos).any()
+    u = rng.integers(0, 2, (9, 504))
+    X = lu.encode(u)
+    assert (X[:, lu.info_bits_pos] == u).all() and all(code.syndrome(x)[0] == 0 for x in X)
+    assert np.mean(lu.info_bits_pos < 504) > 0.9                                  # parity at the end wherever H allows
+    # the same codeword space as IDENTITY: re-encoding IDENTITY's codeword from its LU_DEC information positions returns it
+    Xi = q.Encoder(code, "IDENTITY").encode(np.array(kat["data"]))
+    assert (lu.encode(Xi[:, lu.info_bits_pos]) == Xi).all()
+    for name in ("NR_1_0_2.qc", "NR_2_6_52_rm_half.qc", "test.qc"):            # 5G base graphs of the reference: H2 (last M columns) invertible or refused
+        c = q.Code.from_qc(os.path.join(gold, name))
+        try:
+            e = q.Encoder(c, "QC")
+        except q.QldpcError as ex:
+            assert "not invertible" in str(ex)
+            continue
+        assert e.K == c.N - c.M and (e.info_bits_pos == np.arange(e.K)).all()
+        u = rng.integers(0, 2, (5, e.K))
+        X = e.encode(u)
+        assert (X[:, :e.K] == u).all() and all(c.syndrome(x)[0] == 0 for x in X)
+    with pytest.raises(q.QldpcError):
+        q.Encoder(code, "CHOLESKY")
+
+
 def test_encoder_ira_and_roundtrip_full_size(q, O, torch):
     """config 2 code at full size: encode -> BSC 2 % -> decode == codeword; 64 frames vs the oracle."""
     code = q.Code.ira(65536, 52429, 0.125, 11, 3, 7)
