@@ -110,14 +110,23 @@ template <int V> __device__ __forceinline__ void qk_load(float (&d)[V], const __
         d[0] = __low2float(a); d[1] = __high2float(a); d[2] = __low2float(b); d[3] = __high2float(b);
     }
 }
+/* two floats -> one dword of two binary16 values, round to nearest even: v_cvt_pk_f16_f32 (one instruction on gfx950; the scalar
+ * form is v_cvt_f16_f32 + v_cvt_f16_f32_sdwa + a merge) */
+typedef float qk_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 qk_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t qk_pack_h2(float lo, float hi)
+{
+    const qk_f32x2 f = {lo, hi};
+    const qk_f16x2 h = __builtin_convertvector(f, qk_f16x2);
+    return *reinterpret_cast<const uint32_t *>(&h);
+}
 template <int V> __device__ __forceinline__ void qk_store(__half *p, const float (&d)[V])
 {
     if constexpr (V == 1) p[0] = __float2half_rn(d[0]);
-    else if constexpr (V == 2) *reinterpret_cast<__half2 *>(p) = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1]));
+    else if constexpr (V == 2) *reinterpret_cast<uint32_t *>(p) = qk_pack_h2(d[0], d[1]);
     else {
-        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1])), b = __halves2half2(__float2half_rn(d[2]), __float2half_rn(d[3]));
         uint2 t;
-        t.x = *reinterpret_cast<const uint32_t *>(&a); t.y = *reinterpret_cast<const uint32_t *>(&b);
+        t.x = qk_pack_h2(d[0], d[1]); t.y = qk_pack_h2(d[2], d[3]);
         *reinterpret_cast<uint2 *>(p) = t;
     }
 }
@@ -145,17 +154,20 @@ template <int V> __device__ __forceinline__ void qk_ldm(float (&d)[V], const __h
 template <int V> __device__ __forceinline__ void qk_stm(__half *p, const float (&d)[V])
 {
     if constexpr (V == 1) __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(d[0])), reinterpret_cast<unsigned short *>(p));
-    else if constexpr (V == 2) {
-        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1]));
-        __builtin_nontemporal_store(*reinterpret_cast<const unsigned *>(&a), reinterpret_cast<unsigned *>(p));
-    } else {
-        const __half2 a = __halves2half2(__float2half_rn(d[0]), __float2half_rn(d[1])), b = __halves2half2(__float2half_rn(d[2]), __float2half_rn(d[3]));
+    else if constexpr (V == 2) __builtin_nontemporal_store(qk_pack_h2(d[0], d[1]), reinterpret_cast<unsigned *>(p));
+    else {
         qk_u32x2 t;
-        t.x = *reinterpret_cast<const unsigned *>(&a); t.y = *reinterpret_cast<const unsigned *>(&b);
+        t.x = qk_pack_h2(d[0], d[1]); t.y = qk_pack_h2(d[2], d[3]);
         __builtin_nontemporal_store(t, reinterpret_cast<qk_u32x2 *>(p));
     }
 }
 /* one element (REMAP check passes: a lane's V frames come from V different rows of the old layout) */
+/* v_writelane_b32: a wave-uniform word into ONE lane of a VGPR (lane is a compile-time constant after unrolling) */
+__device__ __forceinline__ uint32_t qk_wlane(uint32_t old, uint32_t val, int lane)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
+    return old;
+}
 __device__ __forceinline__ float qk_ldm1(const float *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ float qk_ldm1(const __half *p) { return __half2float(__ushort_as_half(__builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p)))); }
 __device__ __forceinline__ void qk_put(float *p, float v) { *p = v; }
@@ -623,10 +635,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
     }
     /* all 2 * UN * V ballot words of this wavefront leave in ONE store instruction: lane 2k carries the k-th sgn word,
      * lane 2k + 1 the k-th hard word, each with its own address (lane-0-only stores cost 2 * UN * V instructions and
-     * showed up in the profile: +16 % on the 8-bit VN pass, where V = 4) */
-    u64 mine = 0;
-    u64 *dst = sgn;
+     * showed up in the profile: +16 % on the 8-bit VN pass, where V = 4).  The words are wave-uniform (SGPR pairs): v_writelane
+     * drops each half into its lane, and the lane works out its own address from the list entry it reloads (selecting words and
+     * addresses with per-lane compares cost 8 v_cndmask per VN and frame set: a third of the VALU work of the binary16 pass) */
     if (want_ballots) {      /* wave-uniform: without the syndrome test nobody reads the ballots of the in-between passes, only those of _compute_post */
+    uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int u = 0; u < UN; u++) {
 #pragma unroll
@@ -639,11 +652,18 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * V + j];
             if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
             const int slot = (u * V + j) * 2;
-            if (lane == slot) { mine = s; dst = sgn + bi; }
-            if (lane == slot + 1) { mine = h; dst = hard + bi; }
+            mlo = qk_wlane(mlo, (uint32_t)s, slot);
+            mhi = qk_wlane(mhi, (uint32_t)(s >> 32), slot);
+            mlo = qk_wlane(mlo, (uint32_t)h, slot + 1);
+            mhi = qk_wlane(mhi, (uint32_t)(h >> 32), slot + 1);
         }
     }
-    if (lane < 2 * UN * V) *dst = mine;      /* a repeated tail entry writes the same value to the same address */
+    if (lane < 2 * UN * V) {      /* a repeated tail entry writes the same value to the same address */
+        const int t = lane >> 1, ul = t / V, jl = t % V;
+        const int il = (i0 + ul < n_list) ? i0 + ul : i0;
+        const size_t bl = ((size_t)g * N + list[il]) * V + jl;
+        ((lane & 1) ? hard : sgn)[bl] = ((u64)mhi << 32) | mlo;
+    }
     }
 #pragma unroll
     for (int u = 0; u < UN; u++) {

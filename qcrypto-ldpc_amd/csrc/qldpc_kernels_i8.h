@@ -312,8 +312,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
     }
     /* all UN x 4 ballot words of the wavefront leave in one store instruction (lane 4u + j carries ballot j of VN u);
      * hard == NULL: the decoder aliases it to sgn, an integer posterior has one sign */
-    u64 mine = 0;
-    u64 *dst = sgn;
+    uint32_t mlo = 0, mhi = 0;      /* v_writelane puts each (wave-uniform) ballot word into its lane: see qk_vn_flood */
 #pragma unroll
     for (int u = 0; u < UN; u++) {
         const short t[QI_V] = {tl[u].x, tl[u].y, th[u].x, th[u].y};
@@ -324,7 +323,8 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
                 u64 s = __ballot(t[j] < 0);
                 const u64 dm = (MODE == QK_VN_FIRST) ? 0ull : done[(size_t)g * QI_V + j];
                 if (dm) s = (s & ~dm) | (sgn[b0 + j] & dm);       /* converged frames keep the ballots they converged with */
-                if (lane == u * QI_V + j) { mine = s; dst = sgn + b0 + j; }
+                mlo = qk_wlane(mlo, (uint32_t)s, u * QI_V + j);
+                mhi = qk_wlane(mhi, (uint32_t)(s >> 32), u * QI_V + j);
             }
         }
         if constexpr (MODE == QK_VN_POST) {
@@ -335,7 +335,13 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
             }
         }
     }
-    if (want_ballots && lane < UN * QI_V) { *dst = mine; if (hard) hard[dst - sgn] = mine; }
+    if (want_ballots && lane < UN * QI_V) {
+        const int ul = lane / QI_V, il = (i0 + ul < n_list) ? i0 + ul : i0;
+        const size_t bl = ((size_t)g * N + list[il]) * QI_V + (lane % QI_V);
+        const u64 mine = ((u64)mhi << 32) | mlo;
+        sgn[bl] = mine;
+        if (hard) hard[bl] = mine;
+    }
 }
 
 /* ------------------------------------------------------------------ horizontal layered ------- */
