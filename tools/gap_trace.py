@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: where the time of one early-exit step goes, kernel by kernel, from a rocprofv3 kernel trace.
-  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 tools/gap_trace.py run [f32|i8|f16]
+  cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 tools/gap_trace.py run [f32|i8|f16] [fixed]
   python3 tools/gap_trace.py read $OUT
 """
 import csv
@@ -26,7 +26,7 @@ if sys.argv[1] == "run":
     mag = torch.full((F,), q.bsc_llr(0.02), dtype=torch.float32, device=dev)
     cls = torch.zeros(code.N, dtype=torch.uint8, device=dev)
     cls[enc.K:] = 1
-    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, enable_syndrome=True, n_frames=F, msg_dtype=dt)
+    dec = q.Decoder(code, enc.K, 50, rule="NMS", rule_param=0.75, enable_syndrome=(len(sys.argv) < 4 or sys.argv[3] != "fixed"), n_frames=F, msg_dtype=dt)
     dec.set_stream(torch.cuda.current_stream())
     out = torch.empty((F, 2048), dtype=torch.int32, device=dev)
     for rep in range(3):

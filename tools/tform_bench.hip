@@ -405,6 +405,69 @@ __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const
     }
 }
 
+// E: form D with buffer addressing.  A row's address is wave-uniform except for lane * 4: as a global_ access the compiler adds the row
+// offset to a per-lane 64-bit pointer (one v_lshl_add_u64 per row, load and store alike); as a raw buffer access the row offset rides in
+// the instruction's SGPR soffset and the lane part is ONE VGPR for the whole kernel: no VALU work per row.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t e_rsrc(const float* base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__global__ __launch_bounds__(256) void e_cn(const float* __restrict__ v2c, float* __restrict__ c2v, const int* __restrict__ slot, int M, size_t E)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bpg = (M + 3) / 4;
+    const int g = blockIdx.x / bpg, c = (blockIdx.x % bpg) * 4 + wave;
+    if (c >= M) return;
+    int s[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) s[k] = slot[c * DC + k];
+    const __amdgpu_buffer_rsrc_t rin = e_rsrc(v2c + (size_t)g * E * 64, E * 256), rout = e_rsrc(c2v + (size_t)g * E * 64, E * 256);
+    const int vo = lane * 4;
+    float v[DC], o[DC];
+#pragma unroll
+    for (int k = 0; k < DC; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, vo, s[k] * 256, 2));
+    fold(v, o);
+#pragma unroll
+    for (int k = 0; k < DC; k++) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[k]), rout, vo, (c * DC + k) * 256, 2);
+}
+template <int DVMAX, int UN>
+__global__ __launch_bounds__(256) void e_vn(const float* __restrict__ c2v, float* __restrict__ v2c, const int* __restrict__ vptr,
+                                            const int* __restrict__ cnslot, int N, size_t E, int v_lo, int v_hi)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nv = v_hi - v_lo;
+    const int bpg = (nv + 4 * UN - 1) / (4 * UN);
+    const int g = blockIdx.x / bpg;
+    const int i0 = ((blockIdx.x % bpg) * 4 + wave) * UN;
+    if (i0 >= nv) return;
+    const __amdgpu_buffer_rsrc_t rin = e_rsrc(c2v + (size_t)g * E * 64, E * 256), rout = e_rsrc(v2c + (size_t)g * E * 64, E * 256);
+    const int vo = lane * 4;
+    int vv[UN], s0[UN], d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { vv[u] = v_lo + min(i0 + u, nv - 1); s0[u] = vptr[vv[u]]; d[u] = vptr[vv[u] + 1] - s0[u]; }
+    int e[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];
+    }
+    float m[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) m[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, vo, e[u][k] * 256, 2));
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) sum += m[u][k];
+        const float t = (float)(vv[u] & 7) + sum;
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t - m[u][k]), rout, vo, (s0[u] + k) * 256, 2);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int M = 13107, K = 52429, N = M + K, G = argc > 1 ? atoi(argv[1]) : 64;
@@ -521,6 +584,11 @@ int main(int argc, char** argv)
             d_vn<12, 2, true, false><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
             d_vn<4, 4, true, false><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
         printf("iteration: A' %.3f ms   D' %.3f ms (%.1f %%)\n", acn + avn2, dcn + dvn2, 100.0 * (dcn + dvn2) / (acn + avn2) - 100.0);
+        float ecn = timeit("E cn  form D, buffer addressing (SGPR row offset)", 2.0 * E, [&] { e_cn<<<gcn, 256>>>(v2c, c2v, d_slot, M, E); });
+        float evn = timeit("E' vn form D', buffer addressing, no LLR rows (2E)", 2.0 * E, [&] {
+            e_vn<12, 2><<<G * ((n11 + 7) / 8), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+            e_vn<4, 4><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, n11, N); });
+        printf("iteration: E' %.3f ms (%.1f %% vs D' %.3f ms)\n", ecn + evn, 100.0 * (ecn + evn) / (dcn + dvn2) - 100.0, dcn + dvn2);
     }
     printf("iteration: B' %.3f ms (%.1f %%)\n", b2cn + b2vn, 100.0 * (b2cn + b2vn) / (acn + avn) - 100.0);
     printf("iteration: A %.3f ms   B %.3f ms (%.1f %%)   B(nt) %.3f ms (%.1f %%)\n", acn + avn, bcn + bvn, 100.0 * (bcn + bvn) / (acn + avn) - 100.0,
