@@ -34,7 +34,7 @@ p = "subcomponents/qber_estim.c"
 s = open(p).read()
 s = s.replace('#include "qber_estim.h"', '#include "qber_estim.h"\n#include "ldpc_reconcile.h"\n#include <stdlib.h>', 1)
 s = s.replace("chosenAlgorithm = ALG_CASCADE_CONTINUE_ROLES;",
-              'chosenAlgorithm = ldpc_selected() ? ALG_LDPC_CONTINUE_ROLES : ALG_CASCADE_CONTINUE_ROLES;', 1)
+              'chosenAlgorithm = ldpc_selectedFor(processBlock) ? ALG_LDPC_CONTINUE_ROLES : ALG_CASCADE_CONTINUE_ROLES;', 1)
 arm = "    case ALG_LDPC_CONTINUE_ROLES:\n      return 81;\n    case ALG_LDPC_FLIP_ROLES:\n      return 81;\n"
 assert s.count(arm) == 2, s.count(arm)
 first = s.index(arm)

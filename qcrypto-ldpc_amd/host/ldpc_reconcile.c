@@ -74,6 +74,16 @@ static float ldpc_planQber(const ProcessBlock *pb)
 }
 
 int ldpc_selected(void) { return g_opt_select >= 0 ? g_opt_select : (getenv("ECD2_LDPC") != NULL); }
+/* The QBER follower's choice for ONE block (qber_estim.c:301): LDPC when it is selected and the rate table has a code for the estimated
+ * error rate.  Beyond the lowest rate (0.5: about 8 % at the configured efficiency) the plan has no code; such a block goes to cascade
+ * from the start instead of ending the daemon with LDPC_ERR_RATE -- unless it is too large for cascade's 16-bit indices. */
+int ldpc_selectedFor(const ProcessBlock *pb)
+{
+    qldpc_recon_msg msg;
+    if (!ldpc_selected()) return 0;
+    if (!g_recon || pb->initialBits >= (1 << 16)) return 1;
+    return qldpc_recon_plan(g_recon, pb->initialBits, pb->localError, &msg) != QLDPC_EUNSUPPORTED;
+}
 int ldpc_gpuPrivAmp(void) { return g_opt_gpu_pa >= 0 ? g_opt_gpu_pa : (getenv("ECD2_GPU_PA") != NULL); }
 static int ldpc_maxPacketBytes(void)
 {
@@ -285,14 +295,20 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
     uint32_t *parity;
     unsigned int parityWords, perPacket, fragCount, f;
     int rc, errorCode = 0;
+    float qplan;
 
-    rc = qldpc_recon_plan(g_recon, pb->workbits, ldpc_planQber(pb), &msg);
+    qplan = ldpc_planQber(pb);
+    rc = qldpc_recon_plan(g_recon, pb->workbits, qplan, &msg);
+    if (rc == QLDPC_EUNSUPPORTED && qplan > pb->localError) {      /* the margin pushed the plan off the rate table: plan for the estimate itself */
+        qplan = pb->localError;
+        rc = qldpc_recon_plan(g_recon, pb->workbits, qplan, &msg);
+    }
     if (rc == QLDPC_EUNSUPPORTED) return LDPC_ERR_RATE;
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
     parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
     parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
     if (!parity) return 43;
-    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, ldpc_planQber(pb), &msg, parity, (int)parityWords);
+    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, qplan, &msg, parity, (int)parityWords);
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
     {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits */
         const int n = g_opt_fault >= 0 ? g_opt_fault : ldpc_envInt("ECD2_LDPC_FAULT", 0), disclosed = (int)(msg.code_m - msg.n_punct);

@@ -80,6 +80,7 @@ int ldpc_init(int device);
  *  fallback, `-L p<bytes>` largest parity packet; several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
 int ldpc_parseOption(const char *optarg);
 int ldpc_selected(void);          /**< 1 after `-L 1` (or ECD2_LDPC=1 in the environment) */
+int ldpc_selectedFor(const ProcessBlock *pb);      /**< the per-block choice: selected AND the rate table covers the block's estimated QBER */
 int ldpc_gpuPrivAmp(void);        /**< 1 after `-L g` (or ECD2_GPU_PA=1)                   */
 void ldpc_shutdown(void);
 

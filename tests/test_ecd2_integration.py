@@ -30,6 +30,12 @@ def epochs(seed, n_epochs, bits_per_epoch, qber):
     return a, b
 
 
+# Tests that assert "this block went through LDPC" plan with two sigma of margin on the sampled QBER (`-L m20`): each daemon run draws its own
+# sample, and at m0 a few per cent of short blocks get a plan the true error rate exceeds -- they fall back to cascade, correctly, but a
+# test that greps for "decoded" would then fail one run in twenty.
+LDPC = "1,m20"
+
+
 def need(binary):
     p = os.path.join(REF_DIR, binary)
     if not os.path.exists(p):
@@ -75,7 +81,7 @@ def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
     ~55 cascade packets each way; both daemons write identical final keys."""
     binary = need("ecd2_ldpc")
     a, b = epochs(2, n_epochs, bits, qber)
-    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1"])
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", LDPC])
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0, out["b_log"][-2500:]
     assert (out["a_final"]["words"] == out["b_final"]["words"]).all()
@@ -98,7 +104,7 @@ def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
     through the CPU run below with the SAME daemons, that it is the reference's hash."""
     binary = need("ecd2_ldpc")
     a, b = epochs(5, 4, 15001, 0.02)
-    gpu = run_loopback(binary, tmp_path / "gpu", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"})
+    gpu = run_loopback(binary, tmp_path / "gpu", a, b, env_extra={"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"}, extra_args=["-L", "m20"])
     assert gpu["a_final"] is not None and (gpu["a_final"]["words"] == gpu["b_final"]["words"]).all()
     # Bob on the GPU hash, Alice on the reference's CPU loop: the two final keys must still be identical
     d = tmp_path / "mixed"
@@ -114,7 +120,7 @@ def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
     def start(side, send, recv, env):
         e = dict(os.environ); e.update(env)
         return subprocess.Popen([binary, "-c", side + "_cmd", "-s", send, "-r", recv, "-d", side + "/raw", "-f", side + "/final", "-l", side + "/notify",
-                                 "-q", side + "/resp", "-Q", side + "_q", "-V", "5"], cwd=d, env=e, stdout=open(d / (side + ".log"), "w"), stderr=subprocess.STDOUT)
+                                 "-q", side + "/resp", "-Q", side + "_q", "-V", "5", "-L", "m20"], cwd=d, env=e, stdout=open(d / (side + ".log"), "w"), stderr=subprocess.STDOUT)
     pa = start("a", "a2b", "b2a", {"ECD2_LDPC": "1"})                          # CPU privacy amplification (reference loop)
     pb = start("b", "b2a", "a2b", {"ECD2_LDPC": "1", "ECD2_GPU_PA": "1"})     # GPU privacy amplification
     try:
@@ -140,7 +146,7 @@ def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
     """same epochs through both daemons: both reconcile; LDPC leaks M+32 bits, cascade its parity count."""
     a, b = epochs(3, 4, 6001, 0.02)
     o1 = run_loopback(need("ecd2_cascade"), tmp_path / "c", a, b)
-    o2 = run_loopback(need("ecd2_ldpc"), tmp_path / "l", a, b, env_extra={"ECD2_LDPC": "1"})
+    o2 = run_loopback(need("ecd2_ldpc"), tmp_path / "l", a, b, env_extra={"ECD2_LDPC": "1"}, extra_args=["-L", "m20"])
     for o in (o1, o2):
         assert o["a_final"] is not None and (o["a_final"]["words"] == o["b_final"]["words"]).all()
     assert o1["a_final"]["nbits"] > 0 and o2["a_final"]["nbits"] > 0
@@ -154,7 +160,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
     parity + CRC bits stay in leakageBits."""
     binary = need("ecd2_ldpc")
     a, b = epochs(7, 4, 6001, 0.02)
-    clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"})
+    clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"}, extra_args=["-L", "m20"])
     out = run_loopback(binary, tmp_path / "fault", a, b, extra_args=["-L", "1,x600"])
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     assert "no verified codeword" in out["b_log"]
@@ -192,8 +198,8 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
     assert all((sizes[i] + sizes[i + 1]) % 32 for i in range(0, 16, 2))
     a = [rng.integers(0, 2, n).astype(np.uint8) for n in sizes]
     b = [x ^ (rng.random(x.size) < 0.03) for x in a]
-    one = run_loopback(binary, tmp_path / "one", a, b, extra_args=["-L", "1,g"], blocks=[2] * 8, timeout=90)
-    bat = run_loopback(binary, tmp_path / "batch", a, b, extra_args=["-L", "1,g,b4,w1500"], blocks=[2] * 8, timeout=90)
+    one = run_loopback(binary, tmp_path / "one", a, b, extra_args=["-L", LDPC + ",g"], blocks=[2] * 8, timeout=90)
+    bat = run_loopback(binary, tmp_path / "batch", a, b, extra_args=["-L", LDPC + ",g,b4,w1500"], blocks=[2] * 8, timeout=90)
     # the mother codes were all built in ldpc_init: eight blocks of different length later, still the same 32 entries
     assert "ldpc: engine ready" in bat["b_log"]
     for name, o in (("one", one), ("batch", bat)):
@@ -225,7 +231,7 @@ def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
     daemon's privacy amplification leaves no key at all when the sampled error rate comes out high: seen once in ten runs.)"""
     binary = need("ecd2_ldpc")
     a, b = epochs(11, 2, 60001, 0.045)
-    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1,g,p3000"], timeout=150)
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", LDPC + ",g,p3000"], timeout=150)
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     import re
     m = re.search(r"sent parity in (\d+) packet\(s\), (\d+) key bits", out["a_log"])
@@ -249,7 +255,7 @@ def test_sample_without_errors_and_repeated_parity_packets(tmp_path):
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 10000 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
     assert "0 errors corrected" in out["b_log"]
     a2, b2 = epochs(29, 4, 5003, 0.02)
-    dup = run_loopback(binary, tmp_path / "dup", a2, b2, extra_args=["-L", "1,b2,w200"], extra_args_a=["-L", "1,b2,w200,d1"], timeout=90)
+    dup = run_loopback(binary, tmp_path / "dup", a2, b2, extra_args=["-L", LDPC + ",b2,w200"], extra_args_a=["-L", LDPC + ",b2,w200,d1"], timeout=90)
     assert dup["a_final"] is not None and dup["b_final"] is not None, dup["a_log"][-2000:] + "\n----\n" + dup["b_log"][-2000:]
     assert (dup["a_final"]["words"] == dup["b_final"]["words"]).all()
     assert dup["b_log"].count("decoded 1") + dup["b_log"].count(": decoded ") >= 1 and "Segmentation" not in dup["b_log"]
@@ -276,8 +282,8 @@ def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
     import re
     binary = need("ecd2_ldpc")
     a, b = epochs(5, 2, 6001, 0.03)
-    base = run_loopback(binary, tmp_path / "m0", a, b, extra_args=["-L", "1"], timeout=90)
-    marg = run_loopback(binary, tmp_path / "m60", a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,m60"], timeout=90)
+    base = run_loopback(binary, tmp_path / "m10", a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,m10"], timeout=90)
+    marg = run_loopback(binary, tmp_path / "m70", a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,m70"], timeout=90)
     d = []
     for out in (base, marg):
         assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
@@ -289,3 +295,28 @@ def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
     args = [binary, "-c", "c", "-s", "s", "-r", "r", "-d", "d", "-f", "f", "-l", "l", "-q", "q", "-Q", "Q"]
     bad = subprocess.run(args + ["-L", "1,m500"], cwd=str(tmp_path), capture_output=True, text=True, timeout=20)      # out of range: refused while parsing options
     assert bad.returncode != 0 and "engine ready" not in bad.stdout
+
+
+@pytest.mark.gpu
+def test_block_beyond_the_rate_table_goes_to_cascade_from_the_start(tmp_path):
+    """The rate table ends at 0.5: for an estimated QBER of about 10.5 % and more the plan has no code, and the reference itself ends blocks
+    at 15 % (USELESS_ERRORBOUND, qber_estim.c:28-31).  In between, the QBER follower's per-block choice (`ldpc_selectedFor`) hands the block
+    to cascade instead of ending the daemon with error 88; the next block, at 2 %, is LDPC again in the same daemon pair.  Each run draws
+    its own QBER sample (sigma about 1 % here), so the first block may also land on either side of the window: every outcome must be clean."""
+    binary = need("ecd2_ldpc")
+    rng = np.random.default_rng(41)
+    a = [rng.integers(0, 2, 9001).astype(np.uint8) for _ in range(4)]
+    b = [x ^ (rng.random(x.size) < p) for x, p in zip(a, (0.125, 0.125, 0.02, 0.02))]
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-T", "2", "-L", LDPC], blocks=[2, 2], timeout=90, cmd_gaps=(45.0, 0.5))
+    logs = out["a_log"] + out["b_log"]
+    assert "QBER too high for the LDPC rate table" not in logs and "Segmentation" not in logs
+    first, second = out["finals"][0xb0b80000], out["finals"][0xb0b80002]
+    took = ("ldpc" if "ldpc: epoch b0b80000: sent parity" in out["a_log"] else
+            "cascade" if "Prep to send pkt subtype 4" in logs else "ended by the reference" if "Reply mode out of bounds" in logs else "?")
+    print("first block (QBER 12.5 %):", took)
+    assert took != "?", out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:]
+    if took != "ended by the reference":
+        assert first[0] is not None and first[1] is not None, out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:]
+        assert first[0]["nbits"] == first[1]["nbits"] and (first[0]["words"] == first[1]["words"]).all()
+    assert second[0] is not None and second[1] is not None, out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:]
+    assert "ldpc: epoch b0b80002: sent parity" in out["a_log"] and (second[0]["words"] == second[1]["words"]).all()
