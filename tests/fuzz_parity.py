@@ -55,7 +55,11 @@ def layer_graph(code, var, chk):
 
 
 t0, cases, fails = time.time(), 0, 0
+t_say = t0
 while time.time() - t0 < budget:
+    if time.time() - t_say > 60:      # a long run must keep talking (the GPU box takes 7 silent minutes for a hang)
+        t_say = time.time()
+        print("fuzz: %d cases so far, %d mismatches" % (cases, fails), flush=True)
     try:
         code, cname = make_code()
     except q.QldpcError:
