@@ -440,6 +440,12 @@ def main():
         if traffic is None and (F, N, args.msg_dtype, args.rule, args.schedule) == (4096, 65536, "f32", "NMS", "flooding"):
             log("warning: roofline.traffic is null although the workload is the profiled one -- kernel names changed? re-run tools/pmc_summary.py")
 
+    # what this device copies at (read once + written once, non-temporal) in the decoder's access shape: the measured ceiling beside the data sheet's
+    probe = None
+    if rank == 0:
+        probe = {"rows_256B_GBs": q.copy_probe(4 << 30, 6, False, local_rank), "wide_16B_per_lane_GBs": q.copy_probe(4 << 30, 6, True, local_rank),
+                 "what": "hand-written copy kernels of libqldpc (qldpc_copy_probe), 4 GiB read + 4 GiB written per launch, bytes read + bytes written per second"}
+        probe["frac_of_copy"] = achieved / max(probe["rows_256B_GBs"], probe["wide_16B_per_lane_GBs"])
     if rank == 0:
         line = {
             "metric": "reconciled_key_Mbit_s",
@@ -469,7 +475,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "qk_cn_flood (check-node update)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "alg_bytes_per_launch": cn_bytes, "avg_launch_ms": cn_avg_s * 1e3, "launches": cn["launches"],
+                "alg_bytes_per_launch": cn_bytes, "avg_launch_ms": cn_avg_s * 1e3, "launches": cn["launches"], "copy_probe": probe,
                 # "achieved" prices the SURVEY 8d algorithmic bytes (an N x 4 B LLR array per pass); "moved" the bytes the pass really
                 # fetches with coded LLRs (N / 8 B of received-bit ballots per frame)
                 "vn_update": {"achieved": vn_achieved, "frac": vn_achieved / HBM_PEAK_GBS, "moved": vn_moved, "moved_frac": vn_moved / HBM_PEAK_GBS,

@@ -104,6 +104,10 @@ int qldpc_version(void);
 const char *qldpc_strerror(int status);
 const char *qldpc_last_error(void);           /* thread-local text of the last failure          */
 int qldpc_device_count(void);                 /* HIP devices visible (0 on a CPU-only host)     */
+/* Measurement aid (bench.py): the rate at which `device` copies `bytes` (read once + written once, non-temporal) in the decoder's own
+ * access shape -- wide = 0: 256-byte rows, one dword per lane, eight rows in flight per wavefront; wide = 1: 16 bytes per lane.
+ * The figure counts bytes read + bytes written, like the kernels' rooflines.  No reference counterpart. */
+int qldpc_copy_probe(int device, size_t bytes, int reps, int wide, double *gbytes_per_s);
 
 /* ------------------------------------------------------------------ scalar helpers ----------- */
 float qldpc_llr_from_ber(float ber);                          /* LLR(BER) = -log(p/(1-p)) in double, BS/src/main.cpp:20 */

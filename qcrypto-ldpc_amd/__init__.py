@@ -79,6 +79,7 @@ _sig("qldpc_version", C.c_int, [])
 _sig("qldpc_strerror", C.c_char_p, [C.c_int])
 _sig("qldpc_last_error", C.c_char_p, [])
 _sig("qldpc_device_count", C.c_int, [])
+_sig("qldpc_copy_probe", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)])
 _sig("qldpc_llr_from_ber", C.c_float, [C.c_float])
 _sig("qldpc_bsc_llr", C.c_float, [C.c_float])
 _sig("qldpc_binary_entropy", C.c_float, [C.c_float])
@@ -150,6 +151,14 @@ def version():
 
 def device_count():
     return _L.qldpc_device_count()
+
+
+def copy_probe(nbytes=1 << 30, reps=10, wide=False, device=0):
+    """GB/s (bytes read + bytes written) this device copies at in the decoder's access shape (qldpc_copy_probe): a measured ceiling
+    to read the kernels' rates against."""
+    out = C.c_double(0.0)
+    _chk(_L.qldpc_copy_probe(int(device), int(nbytes), int(reps), 1 if wide else 0, C.byref(out)), "copy_probe")
+    return out.value
 
 
 def llr_from_ber(p):

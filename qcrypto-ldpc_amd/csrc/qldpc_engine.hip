@@ -27,6 +27,69 @@ extern "C" int qldpc_device_count(void)
     return n;
 }
 
+/* ------------------------------------------------------------------ bandwidth probe ---------- */
+
+/* What this device sustains for the access shape the decoder is made of: 256-byte rows, one dword per lane, non-temporal, read + written
+ * once.  bench.py prints it next to the kernels' rates (the 8 TB/s of the data sheet is not reachable by any kernel: DESIGN section 3.1). */
+typedef float qk_probe_f4 __attribute__((ext_vector_type(4)));
+template <int ROWS, bool WIDE>
+static __global__ __launch_bounds__(256) void qk_copy_probe(const float *__restrict__ src, float *__restrict__ dst, size_t n_rows)
+{
+    /* one wavefront per ROWS consecutive 256-byte rows (WIDE: ROWS / 4 KiB-rows), every load issued before the first store: the shape of a
+     * variable-node pass without its arithmetic */
+    const int lane = threadIdx.x & 63;
+    const size_t r0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (r0 >= n_rows) return;
+    if constexpr (WIDE) {
+        qk_probe_f4 v[ROWS / 4];
+#pragma unroll
+        for (int k = 0; k < ROWS / 4; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const qk_probe_f4 *>(src + (r0 + 4 * k) * 64) + lane);
+#pragma unroll
+        for (int k = 0; k < ROWS / 4; k++) __builtin_nontemporal_store(v[k], reinterpret_cast<qk_probe_f4 *>(dst + (r0 + 4 * k) * 64) + lane);
+    } else {
+        float v[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) v[k] = __builtin_nontemporal_load(src + (r0 + k) * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < ROWS; k++) __builtin_nontemporal_store(v[k], dst + (r0 + k) * 64 + lane);
+    }
+}
+
+extern "C" int qldpc_copy_probe(int device, size_t bytes, int reps, int wide, double *gbytes_per_s)
+{
+    int ndev = 0;
+    if (!gbytes_per_s || reps < 1 || bytes < (1u << 20)) return QLDPC_EINVAL;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { qldpc_set_error("no HIP device visible: libqldpc has no CPU fallback"); return QLDPC_ENODEV; }
+    if (device < 0 || device >= ndev) return QLDPC_ENODEV;
+    HIPCHK(hipSetDevice(device));
+    const size_t n_rows = bytes / 256 / 64 * 64;      /* whole workgroups of 4 x 16 rows */
+    const unsigned blocks = (unsigned)(n_rows / 64);
+    float *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = QLDPC_OK;
+    float ms = 0.0f;
+    if (hipMalloc((void **)&a, n_rows * 256) != hipSuccess || hipMalloc((void **)&b, n_rows * 256) != hipSuccess) { rc = QLDPC_ENOMEM; goto out; }
+    if (hipMemset(a, 0, n_rows * 256) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = QLDPC_EHIP; goto out; }
+    if (wide) hipLaunchKernelGGL((qk_copy_probe<16, true>), dim3(blocks), dim3(256), 0, 0, a, b, n_rows);      /* warm-up */
+    else hipLaunchKernelGGL((qk_copy_probe<16, false>), dim3(blocks), dim3(256), 0, 0, a, b, n_rows);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; i++) {
+        const float *from = (i & 1) ? b : a;
+        float *to = (i & 1) ? a : b;
+        if (wide) hipLaunchKernelGGL((qk_copy_probe<16, true>), dim3(blocks), dim3(256), 0, 0, from, to, n_rows);
+        else hipLaunchKernelGGL((qk_copy_probe<16, false>), dim3(blocks), dim3(256), 0, 0, from, to, n_rows);
+    }
+    (void)hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) { rc = QLDPC_EHIP; goto out; }
+    *gbytes_per_s = 2.0 * (double)(n_rows * 256) * reps / ((double)ms * 1e-3) / 1e9;
+out:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (rc == QLDPC_EHIP) qldpc_set_error("copy probe: HIP error");
+    return rc;
+}
+
 /* ------------------------------------------------------------------ decoder object ----------- */
 
 QLDPC_DECLARE_LAUNCH(1)

@@ -41,6 +41,8 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one()
     assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 4096
     r = d["roofline"]
     assert r["traffic"] is not None and 0.95 < r["traffic"] / r["alg_bytes_per_launch"] < 1.1      # PMC traffic of the check pass ~ its algorithmic bytes
+    cp = r["copy_probe"]      # the device's own copy rate, measured in the same run: the check pass runs at (nearly) all of it
+    assert 4000 < cp["rows_256B_GBs"] < 8000 and 4000 < cp["wide_16B_per_lane_GBs"] < 8000 and 0.85 < cp["frac_of_copy"] < 1.15
     fracs = [r["frac"], r["vn_update"]["frac"], r["vn_update"]["moved_frac"], r["whole_step"]["frac"], r["whole_step"]["moved_frac"]]
     assert r["vn_update"]["moved_bytes_per_pass"] < r["vn_update"]["alg_bytes_per_pass"]              # coded LLRs: fewer bytes than SURVEY 8d prices
     e = d["early_exit"]
