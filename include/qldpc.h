@@ -359,6 +359,10 @@ int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, 
  * key untouched.  corrected_bits / leaked_bits / iterations may be NULL. */
 int qldpc_recon_decode(qldpc_recon *r, uint32_t *key_words, int key_bits, float qber, const qldpc_recon_msg *msg,
                        const uint32_t *parity_words, int *corrected_bits, int *leaked_bits, int *iterations);
+/* Alice, second round (incremental redundancy): the parity bits of a plan already made -- `msg` as qldpc_recon_encode left it, with
+ * n_punct lowered by the caller (0 = every parity bit of the mother code).  Same codeword, lower effective rate; Bob decodes again with
+ * qldpc_recon_decode* and the new header.  The ecd2 handlers use it when a verdict asks for the withheld bits (ldpc_reconcile.c). */
+int qldpc_recon_encode_planned(qldpc_recon *r, const uint32_t *key_words, int key_bits, qldpc_recon_msg *msg, uint32_t *parity_words, int cap);
 /* Bob, n blocks that share one plan (same key_bits / rate / code dims) in one launch.
  * key_words[n][ceil(key_bits/32)], parity_words[n][ceil(code_m/32)] (row i holds qldpc_recon_parity_words(&msgs[i]) words),
  * status[n] = QLDPC_OK / QLDPC_EDECODE / QLDPC_ESIZE (that block's header does not match it). */

@@ -532,6 +532,7 @@ _sig("qldpc_recon_create", C.c_int, [C.POINTER(ReconCfg), C.POINTER(_vp)])
 _sig("qldpc_recon_free", None, [_vp])
 _sig("qldpc_recon_plan", C.c_int, [_vp, C.c_int, C.c_float, C.POINTER(ReconMsg)])
 _sig("qldpc_recon_encode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, C.c_int])
+_sig("qldpc_recon_encode_planned", C.c_int, [_vp, _up, C.c_int, C.POINTER(ReconMsg), _up, C.c_int])
 _sig("qldpc_recon_decode", C.c_int, [_vp, _up, C.c_int, C.c_float, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
 _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.POINTER(ReconMsg), _up, _ip, _ip, _ip])
 _sig("qldpc_recon_encode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip])
@@ -627,6 +628,15 @@ class Recon:
         par = np.zeros(self.parity_words(m), np.uint32)
         _chk(_L.qldpc_recon_encode(self._h, kw.ctypes.data_as(_up), int(key_bits), float(qber), C.byref(m),
                                    par.ctypes.data_as(_up), par.size), "Recon.encode")
+        return m, par
+
+    def encode_planned(self, key_words, key_bits, msg, n_punct=0):
+        """Alice, second round: the parity bits of the plan in `msg` with only `n_punct` of them withheld (0 = all) -> (msg2, parity_words)."""
+        kw = np.ascontiguousarray(key_words, dtype=np.uint32)
+        m = ReconMsg.from_buffer_copy(msg)
+        m.n_punct = int(n_punct)
+        par = np.zeros(self.parity_words(m), np.uint32)
+        _chk(_L.qldpc_recon_encode_planned(self._h, kw.ctypes.data_as(_up), int(key_bits), C.byref(m), par.ctypes.data_as(_up), par.size), "Recon.encode_planned")
         return m, par
 
     def decode(self, key_words, key_bits, qber, msg, parity_words):

@@ -480,6 +480,21 @@ extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int
     return qldpc_recon_encode_blocks(r, 1, &k, &key_bits, &qber, msg, &p, &cap);
 }
 
+/*
+ * Alice, second round: the parity bits of a plan that is already on the table (msg as qldpc_recon_plan / qldpc_recon_encode left it, n_punct
+ * possibly lowered by the caller -- 0 = every parity bit of the mother code).  After a failed decode the bits withheld by puncturing are
+ * the cheapest thing to send next (incremental redundancy): the same codeword, a lower effective rate.  msg->crc32 is (re)written.
+ */
+extern "C" int qldpc_recon_encode_planned(qldpc_recon *r, const uint32_t *key_words, int key_bits, qldpc_recon_msg *msg, uint32_t *parity_words, int cap)
+{
+    if (!r || !key_words || !msg || !parity_words) return QLDPC_EINVAL;
+    int rc;
+    if ((rc = check_msg(r, msg, key_bits))) return rc;
+    if (cap < qldpc_recon_parity_words(msg)) { qldpc_set_error("recon_encode_planned: parity buffer holds %d words, need %d", cap, qldpc_recon_parity_words(msg)); return QLDPC_ESIZE; }
+    HIPCHK(hipSetDevice(r->cfg.device));
+    return encode_group(r, 1, &key_words, &key_bits, &msg, &parity_words);
+}
+
 /* blocks of ONE entry (same K, M), possibly of different length and puncturing: one launch.  key[i] is decoded in place. */
 static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *key_bits, const float *qber, const qldpc_recon_msg *const *msgs,
                         const uint32_t *const *parity, int *const *status, int *const *corrected, int *const *iterations)

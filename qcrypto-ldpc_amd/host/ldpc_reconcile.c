@@ -25,7 +25,7 @@ static qldpc_recon *g_recon = NULL;
 static int ldpc_batchSize(void);
 
 /* ---- options: the daemon's -L letter (ecd2.c:26), with the environment as the fall-back for unmodified command lines ---------- */
-static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_margin = 0;
+static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_margin = 0, g_opt_second = 1;
 static int g_batch = -1, g_wait_ms = -1;
 
 static int ldpc_envInt(const char *name, int dflt)
@@ -51,6 +51,7 @@ int ldpc_parseOption(const char *optarg)
         case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* fault injection (tests): flip n disclosed parity bits */
         case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* fault injection (tests): send every parity packet n more times */
         case 'm': g_opt_margin = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_margin < 0 || g_opt_margin > 100) return 1; break;   /* plan for qber + n/10 sigma of its estimate */
+        case 'r': g_opt_second = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* r0: no second round, a failed decode goes straight to cascade */
         case 'y': g_opt_badhdr = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* fault injection (tests): claim another rate index in the header */
         default: return 1;
         }
@@ -288,12 +289,44 @@ int ldpc_prepareAsQberInitiator(ProcessBlock *pb, ALGORITHM_DECISION chosenAlgor
 
 /* ---- EC initiator ("Alice"): one parity packet ------------------------------------------------- */
 
+/* the parity words of one message as subtype-9 packets: one if it fits under transferd's cap, else consecutive slices with the same header */
+static int ldpc_sendParityPackets(ProcessBlock *pb, const qldpc_recon_msg *msg, const uint32_t *parity, unsigned int parityWords, unsigned int *fragCountOut)
+{
+    const unsigned int perPacket = ((unsigned int)ldpc_maxPacketBytes() - sizeof(EcPktHdr_LdpcParity)) / WORD_SIZE;
+    unsigned int fragCount = (parityWords + perPacket - 1) / perPacket, f;
+    int errorCode = 0;
+    if (fragCount < 1) fragCount = 1;
+    if (fragCount > LDPC_MAX_FRAGMENTS) return LDPC_ERR_PKT_SIZE;
+    for (f = 0; f < fragCount && !errorCode; f++) {
+        const unsigned int off = f * perPacket, words = (parityWords - off < perPacket) ? parityWords - off : perPacket;
+        EcPktHdr_LdpcParity *h9;
+        if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE, pb))) break;
+        h9->rateIndex = msg->rate_index + (unsigned int)g_opt_badhdr; h9->keyBits = msg->key_bits; h9->codeK = msg->code_k; h9->codeM = msg->code_m;
+        h9->crc32 = msg->crc32; h9->nPunct = msg->n_punct;
+        h9->fragIndex = f; h9->fragCount = fragCount; h9->fragWordOffset = off;
+        memcpy(&h9[1], parity + off, words * WORD_SIZE);
+        {
+            int d;
+            for (d = 0; d < g_opt_dup && !errorCode; d++) {      /* tests only: the same packet again */
+                char *copy = malloc2(h9->base.totalLengthInBytes);
+                if (!copy) { errorCode = 43; break; }
+                memcpy(copy, h9, h9->base.totalLengthInBytes);
+                errorCode = comms_insertSendPacket(copy, h9->base.totalLengthInBytes);
+            }
+        }
+        if (!errorCode) errorCode = comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
+        else free2(h9);
+    }
+    *fragCountOut = fragCount;
+    return errorCode;
+}
+
 int ldpc_initiateAfterQber(ProcessBlock *pb)
 {
     LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
     qldpc_recon_msg msg;
     uint32_t *parity;
-    unsigned int parityWords, perPacket, fragCount, f;
+    unsigned int parityWords, fragCount = 0;
     int rc, errorCode = 0;
     float qplan;
 
@@ -310,7 +343,7 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
     if (!parity) return 43;
     rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, qplan, &msg, parity, (int)parityWords);
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
-    {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits */
+    {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits (of the FIRST message) */
         const int n = g_opt_fault >= 0 ? g_opt_fault : ldpc_envInt("ECD2_LDPC_FAULT", 0), disclosed = (int)(msg.code_m - msg.n_punct);
         int i;
         for (i = 0; i < n && i < disclosed; i++) {
@@ -318,38 +351,42 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
             parity[pos / 32] ^= 1u << (31 - pos % 32);
         }
     }
-    /* one packet if it fits under transferd's cap, else consecutive slices with the same header */
-    perPacket = ((unsigned int)ldpc_maxPacketBytes() - sizeof(EcPktHdr_LdpcParity)) / WORD_SIZE;
-    fragCount = (parityWords + perPacket - 1) / perPacket;
-    if (fragCount < 1) fragCount = 1;
-    if (fragCount > LDPC_MAX_FRAGMENTS) { free2(parity); return LDPC_ERR_PKT_SIZE; }
-    for (f = 0; f < fragCount && !errorCode; f++) {
-        const unsigned int off = f * perPacket, words = (parityWords - off < perPacket) ? parityWords - off : perPacket;
-        EcPktHdr_LdpcParity *h9;
-        if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE, pb))) break;
-        h9->rateIndex = msg.rate_index + (unsigned int)g_opt_badhdr; h9->keyBits = msg.key_bits; h9->codeK = msg.code_k; h9->codeM = msg.code_m;
-        h9->crc32 = msg.crc32; h9->nPunct = msg.n_punct;
-        h9->fragIndex = f; h9->fragCount = fragCount; h9->fragWordOffset = off;
-        memcpy(&h9[1], parity + off, words * WORD_SIZE);
-        {
-            int d;
-            for (d = 0; d < g_opt_dup && !errorCode; d++) {      /* tests only: the same packet again */
-                char *copy = malloc2(h9->base.totalLengthInBytes);
-                if (!copy) { errorCode = 43; break; }
-                memcpy(copy, h9, h9->base.totalLengthInBytes);
-                errorCode = comms_insertSendPacket(copy, h9->base.totalLengthInBytes);
-            }
-        }
-        if (!errorCode) errorCode = comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
-        else free2(h9);
-    }
+    errorCode = ldpc_sendParityPackets(pb, &msg, parity, parityWords, &fragCount);
     free2(parity);
     if (errorCode) return errorCode;
     ld->rateIndex = msg.rate_index; ld->codeK = msg.code_k; ld->codeM = msg.code_m;
+    ld->msg = msg; ld->planQber = qplan; ld->round = 0;
     pb->processingState = PSTATE_PERFORMED_PARITY;
     pb->leakageBits += qldpc_recon_leaked_bits(&msg);            /* disclosed parity bits + CRC */
     printf("ldpc: epoch %08x: sent parity in %u packet(s), %d key bits, rate index %u, K %u, M %u, %u punctured, %d bits disclosed\n", pb->startEpoch, fragCount,
            pb->workbits, msg.rate_index, msg.code_k, msg.code_m, msg.n_punct, qldpc_recon_leaked_bits(&msg));
+    fflush(stdout);
+    return 0;
+}
+
+/* second round (verdict 2): the parity bits the plan withheld -- the whole parity of the same codeword, header with nPunct = 0.  The bits of
+ * the first message are among them (evenly spaced puncturing), so the block's leak becomes codeM + 32. */
+static int ldpc_sendWithheldParity(ProcessBlock *pb)
+{
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    qldpc_recon_msg msg = ld->msg;
+    const int already = qldpc_recon_leaked_bits(&ld->msg);
+    uint32_t *parity;
+    unsigned int parityWords, fragCount = 0;
+    int rc, errorCode;
+    msg.n_punct = 0;
+    parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
+    parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
+    if (!parity) return 43;
+    rc = qldpc_recon_encode_planned(g_recon, pb->mainBufPtr, pb->workbits, &msg, parity, (int)parityWords);
+    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
+    errorCode = ldpc_sendParityPackets(pb, &msg, parity, parityWords, &fragCount);
+    free2(parity);
+    if (errorCode) return errorCode;
+    ld->round = 1;
+    pb->leakageBits += qldpc_recon_leaked_bits(&msg) - already;
+    printf("ldpc: epoch %08x: second round, sent the %u withheld parity bits too (%u packet(s), %d bits disclosed in all)\n", pb->startEpoch, ld->msg.n_punct, fragCount,
+           qldpc_recon_leaked_bits(&msg));
     fflush(stdout);
     return 0;
 }
@@ -369,6 +406,7 @@ static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *co
     *complete = 0;
     if (pb->processorRole != PROC_ROLE_EC_FOLLOWER || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !ld) return LDPC_ERR_PKT_SIZE;
     if (ld->parityState != 0) return 0;                              /* already complete (queued or decoding): a repeated packet */
+    if (ld->round == 1 && in->nPunct != 0) return 0;                 /* a late copy of the first message after the second round was asked for */
     if (in->base.totalLengthInBytes < sizeof(EcPktHdr_LdpcParity) || in->base.totalLengthInBytes > LDPC_MAX_PACKET_BYTES) return LDPC_ERR_PKT_SIZE;
     if ((int)in->keyBits != pb->workbits || in->nPunct > in->codeM || in->codeM > (1u << 26)) return LDPC_ERR_PKT_SIZE;
     if (in->fragCount < 1 || in->fragCount > LDPC_MAX_FRAGMENTS || in->fragIndex >= in->fragCount) return LDPC_ERR_PKT_SIZE;
@@ -414,11 +452,20 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
     int errorCode;
 
     if ((errorCode = ldpc_createHeader((char **)&h10, SUBTYPE_LDPC_VERDICT, sizeof(EcPktHdr_LdpcVerdict), pb))) return errorCode;
-    h10->decoded = decoded ? 1 : 0;
+    h10->decoded = decoded ? 1 : ((g_opt_second && ld && ld->round == 0 && msg->n_punct > 0 && ld->parityWords) ? 2 : 0);
     h10->correctedBits = (unsigned int)corrected;
     h10->iterations = (unsigned int)iterations;
     if ((errorCode = comms_insertSendPacket((char *)h10, h10->base.totalLengthInBytes))) return errorCode;
 
+    if (!decoded && g_opt_second && ld && ld->round == 0 && msg->n_punct > 0 && ld->parityWords) {
+        /* first failure of a punctured plan: ask for the withheld parity bits instead of giving the block to cascade (the verdict went out
+         * with decoded = 2 below).  mainBufPtr is untouched; the leak is charged when the block ends (the second message repeats the first's bits). */
+        printf("ldpc: epoch %08x: no verified codeword after %d iterations, asking for the %u withheld parity bits\n", pb->startEpoch, iterations, msg->n_punct);
+        fflush(stdout);
+        free2(ld->parityWords);
+        ld->parityWords = NULL; ld->fragsSeen = 0; ld->fragCount = 0; ld->parityState = 0; ld->round = 1;
+        return 0;
+    }
     if (!decoded) {
         /* no codeword found or CRC mismatch: mainBufPtr is untouched, the disclosed bits are spent */
         printf("ldpc: epoch %08x: no verified codeword after %d iterations\n", pb->startEpoch, iterations);
@@ -489,7 +536,10 @@ static int ldpc_flush(void)
         ProcessBlock *pb = pBlkMgmt_getProcessBlk(epochs[i]);      /* finishing a block removes it (privacy amplification): never keep the pointer */
         int e;
         if (!pb) continue;
-        if (status[i] == QLDPC_ESIZE) printf("ldpc: epoch %08x: parity header refused (%s)\n", epochs[i], qldpc_last_error());
+        if (status[i] == QLDPC_ESIZE) {
+            printf("ldpc: epoch %08x: parity header refused (%s)\n", epochs[i], qldpc_last_error());
+            if (pb->algorithmDataPtr) ((LdpcData *)pb->algorithmDataPtr)->round = 1;      /* nothing to ask a second round of: failed verdict */
+        }
         e = ldpc_finishBlock(pb, &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
         if (e && !errorCode) errorCode = e;
     }
@@ -527,6 +577,11 @@ int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
 {
     EcPktHdr_LdpcVerdict *in_head = (EcPktHdr_LdpcVerdict *)receivebuf;
     if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) return LDPC_ERR_PKT_SIZE;
+    if (in_head->decoded == 2) {      /* the follower asks for the withheld parity bits (once) */
+        LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+        if (!ld || ld->round != 0 || ld->msg.n_punct == 0 || pb->processorRole != PROC_ROLE_EC_INITIATOR) return LDPC_ERR_PKT_SIZE;
+        return ldpc_sendWithheldParity(pb);
+    }
     if (!in_head->decoded) {
         if (ldpc_canFallBack(pb)) return ldpc_fallBackToCascade(pb, PROC_ROLE_EC_INITIATOR);
         pBlkMgmt_removeProcessBlk(pb->startEpoch);

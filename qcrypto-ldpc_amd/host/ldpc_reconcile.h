@@ -51,7 +51,8 @@ typedef struct ERRC_LDPC_9 {
 /** @brief subtype 10: verdict */
 typedef struct ERRC_LDPC_10 {
     EcPktHdr_Base base;
-    unsigned int decoded;         /**< 1: follower holds the initiator's key, PA message follows; 0: both sides fall back to cascade (or drop the block if ECD2_LDPC_FALLBACK=0) */
+    unsigned int decoded;         /**< 1: follower holds the initiator's key, PA message follows; 0: both sides fall back to cascade (or drop the block if ECD2_LDPC_FALLBACK=0);
+                                       2: not decoded, send the parity bits the plan withheld (second round: the same header with nPunct = 0), the follower waits for them */
     unsigned int correctedBits;
     unsigned int iterations;
 } EcPktHdr_LdpcVerdict;
@@ -66,6 +67,8 @@ typedef struct ALGORITHM_LDPC_DATA {
     unsigned int fragsSeen;       /**< bit i = fragment i has arrived                                 */
     unsigned int fragCount;
     int parityState;              /**< 0 awaiting fragments, 1 complete and queued / being decoded   */
+    int round;                    /**< 0: first parity message; 1: the withheld bits were asked for (follower) / sent (initiator) */
+    float planQber;               /**< EC initiator: the error rate the block was planned for         */
 } LdpcData;
 
 extern const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_INITIATOR;
@@ -77,7 +80,7 @@ extern const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC;
 int ldpc_init(int device);
 /** the daemon's `-L` option (free in ecd2.c:26's getopt string): `-L 1` = choose LDPC after QBER estimation (qber_estim.c:301),
  *  `-L b<n>` batch size of the batched ingest, `-L w<ms>` its wait, `-L g` privacy amplification on the GPU, `-L f0` no cascade
- *  fallback, `-L p<bytes>` largest parity packet; several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
+ *  fallback, `-L r0` no second round (the withheld parity bits after a failed decode), `-L p<bytes>` largest parity packet; several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
 int ldpc_parseOption(const char *optarg);
 int ldpc_selected(void);          /**< 1 after `-L 1` (or ECD2_LDPC=1 in the environment) */
 int ldpc_selectedFor(const ProcessBlock *pb);      /**< the per-block choice: selected AND the rate table covers the block's estimated QBER */

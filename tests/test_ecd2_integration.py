@@ -161,7 +161,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
     binary = need("ecd2_ldpc")
     a, b = epochs(7, 4, 6001, 0.02)
     clean = run_loopback(binary, tmp_path / "clean", a, b, env_extra={"ECD2_LDPC": "1"}, extra_args=["-L", "m20"])
-    out = run_loopback(binary, tmp_path / "fault", a, b, extra_args=["-L", "1,x600"])
+    out = run_loopback(binary, tmp_path / "fault", a, b, extra_args=["-L", "1,x600,r0"])      # r0: no second round, straight to cascade
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
     assert "no verified codeword" in out["b_log"]
     assert "falling back to cascade as EC follower" in out["b_log"] and "falling back to cascade as EC initiator" in out["a_log"]
@@ -179,7 +179,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
         assert leak + corr > disclosed + 100, (leak, corr, disclosed)
     assert clean["a_final"] is not None and clean["a_final"]["nbits"] > 0
     # dropping instead of falling back is still available
-    drop = run_loopback(binary, tmp_path / "drop", a, b, extra_args=["-L", "1,x600,f0"], timeout=12)
+    drop = run_loopback(binary, tmp_path / "drop", a, b, extra_args=["-L", "1,x600,r0,f0"], timeout=12)
     assert drop["a_final"] is None and drop["b_final"] is None
 
 
@@ -320,3 +320,23 @@ def test_block_beyond_the_rate_table_goes_to_cascade_from_the_start(tmp_path):
         assert first[0]["nbits"] == first[1]["nbits"] and (first[0]["words"] == first[1]["words"]).all()
     assert second[0] is not None and second[1] is not None, out["a_log"][-1500:] + "\n----\n" + out["b_log"][-1500:]
     assert "ldpc: epoch b0b80002: sent parity" in out["a_log"] and (second[0]["words"] == second[1]["words"]).all()
+
+
+@pytest.mark.gpu
+def test_failed_first_decode_gets_the_withheld_parity_bits_instead_of_cascade(tmp_path):
+    """Second round (incremental redundancy): Alice's first parity message is corrupted (`-L x600`), Bob finds no verified codeword and
+    answers with verdict 2; Alice sends the parity bits her plan had punctured (the whole parity of the same codeword, header nPunct = 0),
+    Bob decodes at the mother code's rate.  One more packet instead of the cascade exchange; the block's leak is M + 32 bits."""
+    import re
+    binary = need("ecd2_ldpc")
+    a, b = epochs(7, 4, 6001, 0.02)
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1,x600"])
+    assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-3000:] + "\n----\n" + out["b_log"][-3000:]
+    assert "asking for the" in out["b_log"] and "second round, sent the" in out["a_log"]
+    assert "falling back to cascade" not in out["a_log"] + out["b_log"] and "Prep to send pkt subtype 4\n" not in out["a_log"]
+    assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
+    m = re.search(r"M (\d+), (\d+) punctured", out["a_log"])
+    M, p = int(m.group(1)), int(m.group(2))
+    assert p > 0
+    leaked = int(re.search(r"decoded \d+ key bits in \d+ iterations, \d+ errors corrected, (\d+) bits leaked", out["b_log"]).group(1))
+    assert leaked == M + 32                                          # not (M - p + 32) + (M + 32): the first message's bits are among the second's

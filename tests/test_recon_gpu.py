@@ -214,3 +214,33 @@ def test_one_bad_header_does_not_take_the_batch_down(q):
     st, fixed, co, it = r.decode_blocks(bobs, [12000] * 5, [0.02] * 5, msgs, pars)
     assert list(st) == [0, -6, -6, -6, 0]
     assert (fixed[0] == keys[0]).all() and (fixed[4] == keys[4]).all() and (fixed[2] == bobs[2]).all()
+
+
+def test_second_round_sends_the_withheld_parity_bits(q):
+    """Incremental redundancy: a block planned for a QBER below the true one fails its first decode; Alice sends the parity bits the plan
+    withheld (the same codeword, n_punct = 0: qldpc_recon_encode_planned), Bob decodes again at the mother code's rate.  The first-round bits
+    are a subset of the second round's (evenly spaced pattern), so the leak of the block is M + 32 bits, not the sum of both messages."""
+    rng = np.random.default_rng(77)
+    r = q.Recon()
+    key_bits = 30000
+    a, b, nerr = block(q, rng, key_bits, 0.034)
+    msg, par = r.encode(a, key_bits, 0.022)                      # estimate well below the truth: 0.8 mother punctured towards f = 1.4 at 2.2 %
+    assert msg.n_punct > 0
+    ok, fixed, corrected, leaked, it = r.decode(b, key_bits, 0.022, msg, par)
+    assert not ok and (fixed == b).all()
+    msg2, par2 = r.encode_planned(a, key_bits, msg, 0)
+    assert (msg2.rate_index, msg2.code_k, msg2.code_m, msg2.crc32, msg2.n_punct) == (msg.rate_index, msg.code_k, msg.code_m, msg.crc32, 0)
+    assert par2.size == (msg.code_m + 31) // 32
+    ok2, fixed2, corrected2, leaked2, it2 = r.decode(b, key_bits, 0.034, msg2, par2)
+    assert ok2 and corrected2 == nerr and leaked2 == msg.code_m + 32
+    assert (q.unpack_bits(fixed2, key_bits) == q.unpack_bits(a, key_bits)).all()
+    # the first message's bits are among the second's: bit j of the disclosed list is parity position j + (punctured positions before it)
+    d1 = q.unpack_bits(par, msg.code_m - msg.n_punct)
+    d2 = q.unpack_bits(par2, msg.code_m)
+    M, p = int(msg.code_m), int(msg.n_punct)
+    punct = np.array([((j + 1) * p) // M != (j * p) // M for j in range(M)])      # evenly spaced: position j is withheld when floor((j+1)p/M) steps
+    assert punct.sum() == p and (d2[~punct] == d1).all()
+    with pytest.raises(q.QldpcError):
+        bad = q.ReconMsg.from_buffer_copy(msg)
+        bad.code_m += 32
+        r.encode_planned(a, key_bits, bad, 0)
