@@ -468,6 +468,53 @@ __global__ __launch_bounds__(256) void e_vn(const float* __restrict__ c2v, float
     }
 }
 
+// H: form D' with binary16 message storage (two frames per lane, 128 frames per group: the rows stay 256 bytes), fp32 arithmetic --
+// the engine's binary16 VN pass without its ballots and LLR rebuild.  MODE 0: convert + add + convert; 1: move the dwords only (no VALU work).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <int DVMAX, int UN, int MODE>
+__global__ __launch_bounds__(256) void h_vn(const unsigned* __restrict__ c2v, unsigned* __restrict__ v2c, const int* __restrict__ vptr,
+                                            const int* __restrict__ cnslot, int N, size_t E, int v_lo, int v_hi)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nv = v_hi - v_lo;
+    const int bpg = (nv + 4 * UN - 1) / (4 * UN);
+    const int g = blockIdx.x / bpg;
+    const int i0 = ((blockIdx.x % bpg) * 4 + wave) * UN;
+    if (i0 >= nv) return;
+    const unsigned* in = c2v + (size_t)g * E * 64 + lane;
+    int vv[UN], s0[UN], d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) { vv[u] = v_lo + min(i0 + u, nv - 1); s0[u] = vptr[vv[u]]; d[u] = vptr[vv[u] + 1] - s0[u]; }
+    int e[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) e[u][k] = cnslot[s0[u] + k];
+    }
+    unsigned r[UN][DVMAX];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) r[u][k] = __builtin_nontemporal_load(in + (size_t)e[u][k] * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+        unsigned* out = v2c + ((size_t)g * E + s0[u]) * 64 + lane;
+        if (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < DVMAX; k++) if (k < d[u]) __builtin_nontemporal_store(r[u][k] ^ (unsigned)vv[u], out + (size_t)k * 64);
+            continue;
+        }
+        f2_t m[DVMAX], sum = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) { m[k] = __builtin_convertvector(__builtin_bit_cast(h2_t, r[u][k]), f2_t); sum += m[k]; }
+        const f2_t t = sum + (float)(vv[u] & 7);
+#pragma unroll
+        for (int k = 0; k < DVMAX; k++) if (k < d[u]) __builtin_nontemporal_store(__builtin_bit_cast(unsigned, __builtin_convertvector(t - m[k], h2_t)), out + (size_t)k * 64);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int M = 13107, K = 52429, N = M + K, G = argc > 1 ? atoi(argv[1]) : 64;
@@ -589,6 +636,28 @@ int main(int argc, char** argv)
             e_vn<12, 2><<<G * ((n11 + 7) / 8), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, 0, n11);
             e_vn<4, 4><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, n11, N); });
         printf("iteration: E' %.3f ms (%.1f %% vs D' %.3f ms)\n", ecn + evn, 100.0 * (ecn + evn) / (dcn + dvn2) - 100.0, dcn + dvn2);
+        {   // binary16 storage: half the groups (128 frames each), the same rows
+            const int Gh = G / 2;
+            unsigned *hc = (unsigned*)c2v, *hv = (unsigned*)v2c;
+            timeit("H' vn binary16 rows, fp32 arithmetic, G/2 groups (E)", 1.0 * E, [&] {
+                h_vn<12, 2, 0><<<Gh * ((n11 + 7) / 8), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, 0, n11);
+                h_vn<4, 4, 0><<<Gh * ((N - n11 + 15) / 16), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, n11, N); });
+            timeit("H' vn binary16, 2 x the rows per wavefront (UN 4 / 8)", 1.0 * E, [&] {
+                h_vn<12, 4, 0><<<Gh * ((n11 + 15) / 16), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, 0, n11);
+                h_vn<4, 8, 0><<<Gh * ((N - n11 + 31) / 32), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, n11, N); });
+            timeit("H' vn binary16, UN 2 / 8", 1.0 * E, [&] {
+                h_vn<12, 2, 0><<<Gh * ((n11 + 7) / 8), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, 0, n11);
+                h_vn<4, 8, 0><<<Gh * ((N - n11 + 31) / 32), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, n11, N); });
+            timeit("H' vn binary16, UN 4 / 16", 1.0 * E, [&] {
+                h_vn<12, 4, 0><<<Gh * ((n11 + 15) / 16), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, 0, n11);
+                h_vn<4, 16, 0><<<Gh * ((N - n11 + 63) / 64), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, n11, N); });
+            timeit("H' vn the same rows moved as dwords, no conversion (E)", 1.0 * E, [&] {
+                h_vn<12, 2, 1><<<Gh * ((n11 + 7) / 8), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, 0, n11);
+                h_vn<4, 4, 1><<<Gh * ((N - n11 + 15) / 16), 256>>>(hc, hv, d_vptr, d_cnslot, N, E, n11, N); });
+            timeit("D' vn fp32 on G/2 groups (E): the same bytes as H'", 1.0 * E, [&] {
+                d_vn<12, 2, true, false><<<Gh * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+                d_vn<4, 4, true, false><<<Gh * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
+        }
     }
     printf("iteration: B' %.3f ms (%.1f %%)\n", b2cn + b2vn, 100.0 * (b2cn + b2vn) / (acn + avn) - 100.0);
     printf("iteration: A %.3f ms   B %.3f ms (%.1f %%)   B(nt) %.3f ms (%.1f %%)\n", acn + avn, bcn + bvn, 100.0 * (bcn + bvn) / (acn + avn) - 100.0,
