@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void d_cn(const float* __restrict__ v2c, float
 #pragma unroll
     for (int k = 0; k < DC; k++) stnt(out + (size_t)k * 64, o[k]);
 }
-template <int DVMAX, int UN, bool GATHER = true, bool LLR = true>
+template <int DVMAX, int UN, bool GATHER = true, bool LLR = true, bool FULLWAIT = false>
 __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const float* __restrict__ llr, float* __restrict__ v2c, const int* __restrict__ vptr,
                                             const int* __restrict__ cnslot, int N, size_t E, int v_lo, int v_hi)
 {
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void d_vn(const float* __restrict__ c2v, const
 #pragma unroll
         for (int k = 0; k < DVMAX; k++) if (k < d[u]) m[u][k] = ldnt(in + (size_t)e[u][k] * 64);
     }
+    if (FULLWAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every row in before the first store goes out
 #pragma unroll
     for (int u = 0; u < UN; u++) {
         float sum = 0.f;
@@ -636,6 +637,9 @@ int main(int argc, char** argv)
             e_vn<12, 2><<<G * ((n11 + 7) / 8), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, 0, n11);
             e_vn<4, 4><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, v2c, d_vptr, d_cnslot, N, E, n11, N); });
         printf("iteration: E' %.3f ms (%.1f %% vs D' %.3f ms)\n", ecn + evn, 100.0 * (ecn + evn) / (dcn + dvn2) - 100.0, dcn + dvn2);
+        timeit("D'' vn as D', all loads landed before the first store", 2.0 * E, [&] {
+            d_vn<12, 2, true, false, true><<<G * ((n11 + 7) / 8), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, 0, n11);
+            d_vn<4, 4, true, false, true><<<G * ((N - n11 + 15) / 16), 256>>>(c2v, llr, v2c, d_vptr, d_cnslot, N, E, n11, N); });
         {   // binary16 storage: half the groups (128 frames each), the same rows
             const int Gh = G / 2;
             unsigned *hc = (unsigned*)c2v, *hv = (unsigned*)v2c;
