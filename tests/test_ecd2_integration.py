@@ -212,10 +212,13 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
     assert len(bat["finals"]) == 8
     for st, (fa, fb) in bat["finals"].items():
         assert fa is not None and fb is not None, bat["b_log"][-3000:]
-        assert fa["nbits"] == fb["nbits"] > 0 and (fa["words"] == fb["words"]).all()
+        assert fa["nbits"] == fb["nbits"] and (fa["words"] == fb["words"]).all()
         ref_a, ref_b = one["finals"][st]
         # (key LENGTHS of the two runs are not comparable: the QBER sample comes from /dev/urandom, and with it the rate choice)
         assert ref_a is not None and ref_b is not None and (ref_a["words"] == ref_b["words"]).all()
+    # (a 6 kbit block whose 411-bit sample shows many errors is planned, with the margin, for 5 % and more: what it discloses can leave
+    #  privacy amplification nothing -- an empty final key on BOTH sides is a correct ending, just not a useful one)
+    assert sum(fa["nbits"] > 0 for fa, _ in bat["finals"].values()) >= 6
     import re
     batches = [int(x) for x in re.findall(r"decoded a batch of (\d+) blocks in one call", bat["b_log"])]
     assert sum(batches) == 8 and max(batches) >= 2, batches
@@ -287,9 +290,10 @@ def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
     d = []
     for out in (base, marg):
         assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
-        assert out["a_final"]["nbits"] == out["b_final"]["nbits"] > 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
+        # (with seven sigma of margin the plan may disclose so much that privacy amplification leaves an empty key: equal on both sides is what counts)
+        assert out["a_final"]["nbits"] == out["b_final"]["nbits"] >= 0 and (out["a_final"]["words"] == out["b_final"]["words"]).all()
         d.append(int(re.search(r"(\d+) bits disclosed", out["a_log"]).group(1)))
-    assert d[1] > d[0]      # six sigma of a ~1 000-bit sample at 3 %: about +3 % of QBER (each run draws its own sample: the two estimates differ by ~1.4 sigma)
+    assert base["a_final"]["nbits"] > 0 and d[1] > d[0]      # six sigma of a ~1 000-bit sample at 3 %: about +3 % of QBER (each run draws its own sample: the two estimates differ by ~1.4 sigma)
     assert marg["a_final"]["nbits"] <= base["a_final"]["nbits"]          # and privacy amplification removes what was disclosed
     import subprocess
     args = [binary, "-c", "c", "-s", "s", "-r", "r", "-d", "d", "-f", "f", "-l", "l", "-q", "q", "-Q", "Q"]
