@@ -321,7 +321,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
             if ((rc = dev_alloc(d, &d->d_ybits, G * d->N * V))) return rc;
             if ((rc = dev_alloc(d, &d->d_fmag, G * FG))) return rc;
             if ((rc = dev_alloc(d, &d->d_fnch, G * FG))) return rc;
-            if ((rc = dev_alloc(d, &d->d_vcls, (size_t)d->N))) return rc;
+            if ((rc = dev_alloc(d, &d->d_vcls, ((size_t)d->N + 3) / 4 * 4))) return rc;      /* read as dwords by the kernels */
         }
         if ((rc = dev_alloc(d, &d->d_a, elems))) return rc;
         if ((rc = dev_alloc(d, &d->d_b, elems))) return rc;

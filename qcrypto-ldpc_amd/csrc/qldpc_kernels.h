@@ -330,7 +330,7 @@ struct qk_coded_llr {
     const u64 *ybits;          /* [G][N][V] received bits as ballots                         */
     const float *fmag;         /* [G*FG] |LLR| of a channel bit of each frame (padding: 1)  */
     const int *fnch;           /* [G*FG] class-0 VNs at index >= fnch[f] are pinned (shortening) */
-    const uint8_t *vcls;       /* [N] VN class                                               */
+    const uint8_t *vcls;       /* [N] VN class (allocated to a multiple of 4 bytes: read as dwords) */
     const u64 *ebits;          /* [G][N][V] per-frame erasures as ballots (qldpc_load_erasures_dev), or NULL */
 };
 
@@ -338,7 +338,8 @@ struct qk_coded_llr {
 /* Y of VN v for the V frames of this lane, rebuilt from the coded form (the float the LLR array would hold) */
 template <int V> __device__ __forceinline__ void qk_coded_y(float (&y)[V], const qk_coded_llr &c, int g, int v, int N, int lane, const float (&mg)[V], const int (&nc)[V])
 {
-    const int cls = c.vcls[v];
+    /* v is wave-uniform: the class byte comes out of a scalar dword load (a byte load is a vector load with a round trip and per-lane compares) */
+    const int cls = (int)((reinterpret_cast<const uint32_t *>(c.vcls)[v >> 2] >> ((v & 3) * 8)) & 0xffu);
 #pragma unroll
     for (int j = 0; j < V; j++) {
         const bool bit = (c.ybits[((size_t)g * N + v) * V + j] >> lane) & 1ull;
@@ -549,17 +550,22 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
 #pragma unroll
     for (int u = 0; u < UN; u++) { bb[u] = vn_ptr[vv[u]]; dd[u] = vn_ptr[vv[u] + 1] - bb[u]; }
     float y[UN][V], tmp[UN][V];
-    if constexpr (CODED) {
-        float mg[V];
-        int nc[V];
+    /* the channel values: rebuilt from ballots (CODED) or read as rows.  In the unrolled path this runs AFTER the message rows have been
+     * asked for, so that its own small loads (frame constants, ballot words, class) travel with them instead of in front of them */
+    auto channel = [&]() {
+        if constexpr (CODED) {
+            float mg[V];
+            int nc[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
+            for (int j = 0; j < V; j++) { mg[j] = coded.fmag[(size_t)g * FG + lane * V + j]; nc[j] = coded.fnch[(size_t)g * FG + lane * V + j]; }
 #pragma unroll
-        for (int u = 0; u < UN; u++) qk_coded_y<V>(y[u], coded, g, vv[u], N, lane, mg, nc);
-    } else {
+            for (int u = 0; u < UN; u++) qk_coded_y<V>(y[u], coded, g, vv[u], N, lane, mg, nc);
+        } else {
 #pragma unroll
-        for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
-    }
+            for (int u = 0; u < UN; u++) qk_ldm<V>(y[u], yin + (size_t)vv[u] * FG);
+        }
+    };
+    if constexpr (MODE == QK_VN_FIRST || DVMAX <= 0) channel();
 
     if constexpr (MODE == QK_VN_FIRST) {
 #pragma unroll
@@ -584,6 +590,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_vn_flood(const MT *__restrict__
             for (int k = 0; k < DVMAX; k++)
                 if (k < dd[u]) qk_ldm<V>(m[u][k], cin + (size_t)tr[u][k] * FG);
         }
+        channel();
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             float sum[V];

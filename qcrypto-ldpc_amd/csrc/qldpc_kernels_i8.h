@@ -242,7 +242,7 @@ __global__ __launch_bounds__(QK_THREADS) void qi_vn_flood(const uint32_t *__rest
         for (int j = 0; j < QI_V; j++) { qm[j] = qi_quant1(coded.fmag[(size_t)g * QI_FG + lane * QI_V + j], scale); nc[j] = coded.fnch[(size_t)g * QI_FG + lane * QI_V + j]; }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const int cls = coded.vcls[vv[u]];
+            const int cls = (int)((reinterpret_cast<const uint32_t *>(coded.vcls)[vv[u] >> 2] >> ((vv[u] & 3) * 8)) & 0xffu);
             uint32_t w = 0;
 #pragma unroll
             for (int j = 0; j < QI_V; j++) {
