@@ -78,3 +78,18 @@ def test_puncture_pattern_search_and_message_widths(tmp_path):
     assert len(idx) == n_p == len(set(idx)) and min(idx) >= 11469 and max(idx) < 16384      # parity VNs only
     out16 = run("-N", "8192", "-K", "6554", "-r", "NMS", "-p", "0.75", "-f", "128", "-b", "128", "-s", "0.02:0.02:0.01", "-Q", "16")
     assert "16-bit messages" in out16 and rows(out16)[0]["fe"] == 0
+
+
+def test_encoder_construction_option():
+    """`-G` = p.G_method of the harness (VAR/main.cpp (alist-v1.0.1):135-145) / Encoder_LDPC_from_QC ((qc):145): the loop runs with each
+    construction and decodes (the information positions differ, the code is the same)."""
+    alist = os.path.join(ROOT, "tests", "golden", "PEGReg504x1008.alist")
+    for g in ("IDENTITY", "LU_DEC"):
+        out = run("-a", alist, "-G", g, "-r", "NMS", "-p", "0.75", "-i", "30", "-f", "100", "-b", "100", "-s", "0.02:0.02:0.01")
+        r = rows(out)
+        assert len(r) == 1 and r[0]["fra"] == 100 and r[0]["fe"] <= 2 and "Info. bits (K) = 504" in out
+    out = run("-q", os.path.join(ROOT, "tests", "golden", "NR_1_0_2.qc"), "-G", "QC", "-r", "SPA", "-i", "50", "-f", "100", "-b", "100", "-s", "0.01:0.01:0.01")
+    r = rows(out)
+    assert len(r) == 1 and r[0]["fra"] == 100 and r[0]["fe"] < 60      # N = 136: short code, FER band of README_LDPC.md:937-974 without puncturing is far below
+    p = subprocess.run([SIM, "-a", alist, "-G", "CHOLESKY"], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0
