@@ -327,7 +327,10 @@ typedef struct qldpc_recon_cfg {
     int puncture;          /* 1 (default): puncture parity VNs down to the target efficiency; 0 / 2: disclose all M    */
     int preload;           /* 1: build every (mother size, rate) entry in qldpc_recon_create -- no code construction and no
                               device allocation afterwards for blocks of up to mother_max bits                          */
-    int reserved[2];       /* must be zero */
+    int peg_depth;         /* 0: the information part of every code is the seeded socket shuffle (qldpc_code_ira); 1..4: grown by
+                              progressive edge growth to that depth (qldpc_code_ira_peg; 2 = no 4-cycles), SURVEY.md 8f #3.  Both
+                              sides must use the same value: the codes are derived from (size, rate, peg_depth, seed)          */
+    int reserved[1];       /* must be zero */
 } qldpc_recon_cfg;
 
 /* Travels in the parity packet (all fields uint32, little-endian like every ecd2 header). */
@@ -379,6 +382,10 @@ int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const *key_words,
                               const qldpc_recon_msg *msgs, const uint32_t *const *parity_words, int *status, int *corrected,
                               int *iterations);
 uint32_t qldpc_crc32_words(const uint32_t *words, int n_bits);
+/* The same CRC-32 the way the device verification computes it (rk_verify / rk_crc in qldpc_recon.hip): `lanes` (a power of two) equal
+ * chunks, each run through the byte-wise recurrence from a zero register, folded pairwise with x^len multipliers mod the CRC polynomial,
+ * start value and final inversion applied at the end.  Host mirror for tests: equals qldpc_crc32_words for every length. */
+uint32_t qldpc_crc32_words_chunked(const uint32_t *words, int n_bits, int lanes);
 
 /* ------------------------------------------------------------------ privacy amplification ---- */
 /*

@@ -3,6 +3,11 @@
 # into oracle/_ref/ (git-ignored, travels to the GPU box).  TEST INFRASTRUCTURE ONLY.
 #
 #   oracle/_ref/ecd2_cascade  pristine reference daemon (cascade_biconf): the integration oracle of SURVEY.md section 4
+#   Both test daemons are compiled with -DFIXED_RNG_SEED=<n>, the reference's own switch (subcomponents/rnd.c:145-166, debug.h:62): every
+#   seed the daemon would read from /dev/urandom (QBER sample positions, cascade permutations, the PA hash) is that constant, so a
+#   loopback run is reproducible bit for bit and the tests assert exact key lengths.  ecd2_ldpc additionally gets -DLDPC_TEST_HOOKS
+#   (the fault-injection items of -L: x, d, y).  oracle/_ref/ecd2_ldpc_urandom is the plugin as a maintainer builds it -- seeds from
+#   /dev/urandom, no hooks -- for the soak runs of tests/ecd2_loop.py only.
 #   oracle/_ref/ecd2_ldpc     the same sources with the four maintainer edits of INTEGRATION.md section 2 applied to a
 #                             scratch copy (the two `return 81` arms of subcomponents/qber_estim.c:337-340,420-423, the
 #                             algorithm choice at :301 taken from the new `-L` option (ldpc_selected(); ECD2_LDPC=1 still works),
@@ -23,7 +28,8 @@ cp -r "$REF/errorcorrection" "$REF/packetheaders" "$TMP/"
 chmod -R u+w "$TMP"
 cd "$TMP/errorcorrection"
 SRCS="subcomponents/rnd.c subcomponents/debug.c subcomponents/helpers.c subcomponents/comms.c subcomponents/cascade_biconf.c subcomponents/priv_amp.c subcomponents/qber_estim.c subcomponents/processblock_mgmt.c definitions/algorithms/algorithms.c ecd2.c"
-gcc -O2 -g -w -o "$OUT/ecd2_cascade" $SRCS -lm
+SEED=${ECD2_FIXED_SEED:-0x5eed1234}
+gcc -O2 -g -w -DFIXED_RNG_SEED=$SEED -o "$OUT/ecd2_cascade" $SRCS -lm
 # the reference's own PRNG (subcomponents/rnd.c) as a shared object: pins the oracle's LFSR restatement
 gcc -O2 -w -shared -fPIC -o "$OUT/librefrnd.so" subcomponents/rnd.c
 
@@ -54,7 +60,7 @@ loop = ("    for (i = 0; i < pb->finalKeyBits; i++) { /* go through all targetbi
         "    }\n")
 assert s.count(loop) == 1
 s = s.replace(loop, "    if (ldpc_gpuPrivAmp()) {\n"
-                    "      if (qldpc_privamp(0, pb->mainBufPtr, pb->workbits, seed, pb->finalKeyBits, finalkey)) return 85;\n"
+                    "      if (qldpc_privamp(ldpc_deviceForBlock(pb), pb->mainBufPtr, pb->workbits, seed, pb->finalKeyBits, finalkey)) return 85;\n"
                     "    } else {\n" + loop + "    }\n", 1)
 s = s.replace('#include "priv_amp.h"', '#include "priv_amp.h"\n#include "ldpc_reconcile.h"\n#include <stdlib.h>', 1)
 open(p, "w").write(s)
@@ -96,11 +102,13 @@ s = s.replace('    "Algorithm specific data ptr not null"\n};',
 open(p, "w").write(s)
 PY
 cp "$ROOT/qcrypto-ldpc_amd/host/ldpc_reconcile.c" "$ROOT/qcrypto-ldpc_amd/host/ldpc_reconcile.h" subcomponents/
-gcc -O2 -g -w -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc" $SRCS subcomponents/ldpc_reconcile.c \
+gcc -O2 -g -w -DFIXED_RNG_SEED=$SEED -DLDPC_TEST_HOOKS -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc" $SRCS subcomponents/ldpc_reconcile.c \
+    -L"$ROOT/qcrypto-ldpc_amd" -lqldpc -Wl,-rpath,'$ORIGIN/../../qcrypto-ldpc_amd' -Wl,-rpath,/opt/rocm/lib -lm
+gcc -O2 -g -w -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc_urandom" $SRCS subcomponents/ldpc_reconcile.c \
     -L"$ROOT/qcrypto-ldpc_amd" -lqldpc -Wl,-rpath,'$ORIGIN/../../qcrypto-ldpc_amd' -Wl,-rpath,/opt/rocm/lib -lm
 # optional: the same LDPC daemon with AddressSanitizer on the C sources (host code only), for chasing memory errors: ECD2_ASAN=1
 if [ -n "${ECD2_ASAN:-}" ]; then
-  gcc -O1 -g -w -fsanitize=address -fno-omit-frame-pointer -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc_asan" $SRCS subcomponents/ldpc_reconcile.c \
+  gcc -O1 -g -w -DFIXED_RNG_SEED=$SEED -DLDPC_TEST_HOOKS -fsanitize=address -fno-omit-frame-pointer -I. -Isubcomponents -I"$ROOT/include" -o "$OUT/ecd2_ldpc_asan" $SRCS subcomponents/ldpc_reconcile.c \
       -L"$ROOT/qcrypto-ldpc_amd" -lqldpc -Wl,-rpath,'$ORIGIN/../../qcrypto-ldpc_amd' -Wl,-rpath,/opt/rocm/lib -lm
 fi
-echo "built $OUT/ecd2_cascade and $OUT/ecd2_ldpc"
+echo "built $OUT/ecd2_cascade, $OUT/ecd2_ldpc (fixed seed $SEED, test hooks) and $OUT/ecd2_ldpc_urandom"

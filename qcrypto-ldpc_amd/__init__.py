@@ -518,7 +518,7 @@ class ReconCfg(C.Structure):
     _fields_ = [("device", C.c_int), ("efficiency", C.c_float), ("n_rates", C.c_int), ("rates", C.c_float * 8),
                 ("n_ite", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("key_quantum", C.c_int),
                 ("max_blocks", C.c_int), ("seed", C.c_uint64), ("schedule", C.c_int), ("mother_step", C.c_int), ("mother_max", C.c_int),
-                ("rate_gap", C.c_float), ("puncture", C.c_int), ("preload", C.c_int), ("reserved", C.c_int * 2)]
+                ("rate_gap", C.c_float), ("puncture", C.c_int), ("preload", C.c_int), ("peg_depth", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class ReconMsg(C.Structure):
@@ -538,6 +538,7 @@ _sig("qldpc_recon_decode_batch", C.c_int, [_vp, C.c_int, _up, C.c_int, _fp, C.PO
 _sig("qldpc_recon_encode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip])
 _sig("qldpc_recon_decode_blocks", C.c_int, [_vp, C.c_int, C.POINTER(_up), _ip, _fp, C.POINTER(ReconMsg), C.POINTER(_up), _ip, _ip, _ip])
 _sig("qldpc_crc32_words", C.c_uint32, [_up, C.c_int])
+_sig("qldpc_crc32_words_chunked", C.c_uint32, [_up, C.c_int, C.c_int])
 _sig("qldpc_recon_parity_words", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_leaked_bits", C.c_int, [C.POINTER(ReconMsg)])
 _sig("qldpc_recon_entries_created", C.c_long, [_vp])
@@ -559,8 +560,11 @@ def privamp(key_words, workbits, seed, final_bits, device=0):
     return out
 
 
-def crc32_words(words, n_bits):
+def crc32_words(words, n_bits, lanes=0):
+    """CRC-32 of the key bits; lanes > 0: the chunked fold the device verification uses (same value)"""
     w = np.ascontiguousarray(words, dtype=np.uint32)
+    if lanes:
+        return int(_L.qldpc_crc32_words_chunked(w.ctypes.data_as(_up), int(n_bits), int(lanes)))
     return int(_L.qldpc_crc32_words(w.ctypes.data_as(_up), int(n_bits)))
 
 
@@ -569,7 +573,7 @@ class Recon:
 
     def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=None, rule=None, rule_param=None,
                  key_quantum=1024, max_blocks=1, seed=7, schedule="flooding", mother_step=None, mother_max=None, rate_gap=None,
-                 puncture=True, preload=False):
+                 puncture=True, preload=False, peg_depth=0):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
         cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
@@ -587,7 +591,7 @@ class Recon:
             cfg.mother_max = int(mother_max)
         if rate_gap is not None:
             cfg.rate_gap = float(rate_gap)
-        cfg.puncture, cfg.preload = (1 if puncture else 2), int(bool(preload))
+        cfg.puncture, cfg.preload, cfg.peg_depth = (1 if puncture else 2), int(bool(preload)), int(peg_depth)
         h = _vp()
         _chk(_L.qldpc_recon_create(C.byref(cfg), C.byref(h)), "Recon")
         self._h = h
@@ -699,8 +703,38 @@ class Recon:
                                           co.ctypes.data_as(_ip), it.ctypes.data_as(_ip)), "Recon.decode_blocks")
         return st, kws, co, it
 
+    def prepare_decode(self, keys, key_bits, qber, msgs, parities):
+        """decode_blocks with the argument marshalling done once: returns an object whose run() is the one C call
+        (qldpc_recon_decode_blocks) and nothing else -- what a C caller's timed region contains"""
+        return _PreparedDecode(self, keys, key_bits, qber, msgs, parities)
+
     def __del__(self):
         try:
             _L.qldpc_recon_free(self._h)
         except Exception:
             pass
+
+
+class _PreparedDecode:
+    def __init__(self, recon, keys, key_bits, qber, msgs, parities):
+        self._r = recon
+        self.n = n = len(keys)
+        self._orig = [np.ascontiguousarray(k, dtype=np.uint32) for k in keys]
+        self.keys = [k.copy() for k in self._orig]
+        self._pars = [np.ascontiguousarray(p_, dtype=np.uint32) for p_ in parities]
+        self._kp = (_up * n)(*[k.ctypes.data_as(_up) for k in self.keys])
+        self._pp = (_up * n)(*[p_.ctypes.data_as(_up) for p_ in self._pars])
+        self._kb = np.ascontiguousarray(key_bits, dtype=np.int32)
+        self._qb = np.ascontiguousarray(qber, dtype=np.float32)
+        self._msgs = (ReconMsg * n)(*msgs)
+        self.status, self.corrected, self.iterations = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+
+    def reset(self):
+        """Bob's uncorrected keys again (the decode works in place)"""
+        for k, o in zip(self.keys, self._orig):
+            k[:] = o
+
+    def run(self):
+        _chk(_L.qldpc_recon_decode_blocks(self._r._h, self.n, self._kp, self._kb.ctypes.data_as(_ip), self._qb.ctypes.data_as(_fp), self._msgs, self._pp,
+                                          self.status.ctypes.data_as(_ip), self.corrected.ctypes.data_as(_ip), self.iterations.ctypes.data_as(_ip)),
+             "Recon.decode_blocks")

@@ -343,7 +343,8 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     if ((rc = dev_alloc(d, &d->d_active, 4))) return rc;
     HIPCHK(hipMemset(d->d_active, 0, 4 * sizeof(int)));
     if ((rc = dev_alloc(d, &d->d_work, 1))) return rc;
-    HIPCHK(hipHostMalloc((void **)&d->h_active, 4 * sizeof(int), hipHostMallocMapped));
+    /* coherent (fine-grained): the host spins on a word the kernel releases at system scope while the stream is still running */
+    HIPCHK(hipHostMalloc((void **)&d->h_active, 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     memset(d->h_active, 0, 4 * sizeof(int));
     HIPCHK(hipHostGetDevicePointer((void **)&d->h_active_dev, d->h_active, 0));
     /* active-frame compaction (early exit, flooding, messages not frozen): reserved[0] = 0 auto (batches of >= 4 groups), 1 always, 2 never */

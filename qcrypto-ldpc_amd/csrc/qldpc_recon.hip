@@ -16,6 +16,8 @@
 #include <cstring>
 #include <list>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qldpc.h"
@@ -30,24 +32,34 @@
         }                                                                                               \
     } while (0)
 
+/*
+ * One of the two staging sets of an entry: while batch i decodes, batch i + 1 is copied into the other set's pinned block, sent to
+ * the device and assembled into frames on the lane's copy stream, and batch i - 1's results travel back.
+ */
+struct stage_set {
+    uint32_t *h_in, *d_in;     /* keys [n][Wk] | disclosed parity [n][Wm] | |LLR| [n] | block length [n] | punctured [n] | Alice's CRC [n] */
+    uint32_t *h_res, *d_res;   /* verified key words [n][Wk] | status [n] | bits flipped [n] | iterations [n] | CRC found [n] */
+    uint32_t *d_bits;          /* [max_blocks][Wn]  assembled frames */
+    uint32_t *d_erase;         /* [max_blocks][Wn]  per-frame puncturing masks */
+    hipEvent_t ev_in, ev_out, ev_done;
+};
+
 struct recon_entry {
     int K, M;
     qldpc_code *code;
     qldpc_encoder *enc;
     qldpc_decoder *dec;
     uint8_t *d_cls;       /* [N]: key VNs channel, parity VNs pinned */
-    uint32_t *d_key;      /* [max_blocks][Wk]  key words as handed in (Bob) / information words (Alice) */
-    uint32_t *d_disc;     /* [max_blocks][Wm]  disclosed parity bits, packed */
-    uint32_t *d_bits;     /* [max_blocks][Wn]  assembled frames */
-    uint32_t *d_erase;    /* [max_blocks][Wn]  per-frame puncturing masks */
-    uint32_t *d_out;      /* [max_blocks][Wn] */
-    float *d_mag;         /* [max_blocks] */
+    uint32_t *d_out;      /* [max_blocks][Wn] decoded words / Alice's codewords */
     int *d_iters, *d_ok;  /* [max_blocks] */
-    int *d_nch;           /* [max_blocks] channel VNs per frame (block length) */
-    int *d_np;            /* [max_blocks] punctured parity VNs per frame */
-    /* one pinned host block and one device block per direction: a decode is ONE copy in and ONE copy out */
-    uint32_t *h_in, *d_in;     /* keys [n][Wk] | disclosed parity [n][Wm] | |LLR| [n] | block length [n] | punctured [n] */
-    uint32_t *h_res, *d_res;   /* decoded words [n][Wn] | iterations [n] | success [n] */
+    stage_set set[2];
+    int next_set;
+};
+
+/* a lane = one host worker with a compute stream and a copy stream: the rate groups of a call run side by side, one lane each */
+#define RECON_LANES 4
+struct recon_lane {
+    hipStream_t stream, copy;
 };
 
 struct qldpc_recon {
@@ -56,7 +68,11 @@ struct qldpc_recon {
     std::list<recon_entry> cache;   /* most recently used first */
     size_t keep;                    /* entries the cache may hold (all mother codes when they are preloaded) */
     long created;                   /* entries built so far (tests: nothing is built after a preload) */
+    recon_lane lane[RECON_LANES];
+    int profiling;
 };
+
+#define CRC_POLY 0xEDB88320u      /* CRC-32 (IEEE 802.3), reflected */
 
 static const uint32_t *crc_table()
 {
@@ -65,7 +81,7 @@ static const uint32_t *crc_table()
     if (!init) {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
-            for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? CRC_POLY ^ (c >> 1) : c >> 1;
             t[i] = c;
         }
         init = true;
@@ -87,6 +103,143 @@ extern "C" uint32_t qldpc_crc32_words(const uint32_t *w, int n_bits)
     return c ^ 0xFFFFFFFFu;
 }
 
+/*
+ * The same CRC computed in parallel: the register is linear over GF(2) in (start value, message), so with start value 0 the
+ * register after A || B is reg(A) x^|B| + reg(B) (polynomials mod the CRC polynomial) and the start value 0xFFFFFFFF adds
+ * 0xFFFFFFFF x^|message|.  Every lane runs the byte-wise recurrence over its own chunk (chunks of equal length; zero words in
+ * front of the message leave a zero register alone), the partial registers are folded in a tree -- the same jump-ahead idea the
+ * privacy-amplification kernel uses for the LFSR -- and the two constants are applied at the end.  In the reflected form bit 31
+ * is the coefficient of x^0 and multiplying by x is a right shift.
+ */
+__host__ __device__ static inline uint32_t gf_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & (0x80000000u >> i)) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : (b >> 1);
+    }
+    return p;
+}
+/* x^n mod the CRC polynomial */
+__host__ __device__ static inline uint32_t gf_xpow(unsigned long long n)
+{
+    uint32_t r = 0x80000000u, sq = 0x40000000u;      /* 1, x */
+    while (n) {
+        if (n & 1ull) r = gf_mulmod(r, sq);
+        sq = gf_mulmod(sq, sq);
+        n >>= 1;
+    }
+    return r;
+}
+__host__ __device__ static inline uint32_t crc_word_step(uint32_t c, uint32_t x, const uint32_t *t)
+{
+    for (int b = 3; b >= 0; b--) c = t[(c ^ (x >> (8 * b))) & 0xFF] ^ (c >> 8);
+    return c;
+}
+__host__ __device__ static inline uint32_t tail_mask(int i, int nw, int n_bits)
+{
+    return (i == nw - 1 && (n_bits & 31)) ? 0xFFFFFFFFu << (32 - (n_bits & 31)) : 0xFFFFFFFFu;
+}
+
+/* host mirror of the device verification (rk_verify / rk_crc): `lanes` chunks folded in a tree; equals qldpc_crc32_words */
+extern "C" uint32_t qldpc_crc32_words_chunked(const uint32_t *w, int n_bits, int lanes)
+{
+    if (!w || n_bits <= 0 || lanes < 1 || (lanes & (lanes - 1))) return 0;
+    const uint32_t *t = crc_table();
+    const int nw = (n_bits + 31) / 32;
+    const int c = (nw + lanes - 1) / lanes, pad = c * lanes - nw;
+    std::vector<uint32_t> reg((size_t)lanes, 0u);
+    for (int l = 0; l < lanes; l++)
+        for (int v = l * c; v < (l + 1) * c; v++) {
+            const int i = v - pad;
+            if (i >= 0) reg[(size_t)l] = crc_word_step(reg[(size_t)l], w[i] & tail_mask(i, nw, n_bits), t);
+        }
+    uint32_t X = gf_xpow(32ull * (unsigned long long)c);
+    for (int s = 1; s < lanes; s <<= 1) {
+        for (int l = 0; l + s < lanes; l += 2 * s) reg[(size_t)l] = gf_mulmod(reg[(size_t)l], X) ^ reg[(size_t)(l + s)];
+        X = gf_mulmod(X, X);
+    }
+    return reg[0] ^ gf_mulmod(0xFFFFFFFFu, gf_xpow(32ull * (unsigned long long)nw)) ^ 0xFFFFFFFFu;
+}
+
+/* one workgroup of 256 lanes per block: CRC-32 of words[0 .. ceil(n_bits / 32)) (tail bits masked) by the chunked fold; with `old` also
+ * the number of key bits in which words differs from old, and with `copy_to` the masked words are written out.  Every lane returns the CRC. */
+#define RK_LANES 256
+__device__ static uint32_t rk_block_crc(const uint32_t *__restrict__ words, int n_bits, const uint32_t *__restrict__ old, uint32_t *__restrict__ copy_to,
+                                        int *flips_out, uint32_t *s_tab, uint32_t *s_reg, int *s_cnt)
+{
+    const int t = (int)threadIdx.x;
+    {
+        uint32_t c = (uint32_t)t;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? CRC_POLY ^ (c >> 1) : c >> 1;
+        s_tab[t] = c;
+    }
+    __syncthreads();
+    const int nw = (n_bits + 31) / 32;
+    const int c = (nw + RK_LANES - 1) / RK_LANES, pad = c * RK_LANES - nw;
+    uint32_t reg = 0;
+    int flips = 0;
+    for (int v = t * c; v < (t + 1) * c; v++) {
+        const int i = v - pad;
+        if (i < 0) continue;
+        const uint32_t m = tail_mask(i, nw, n_bits);
+        const uint32_t x = words[i] & m;
+        reg = crc_word_step(reg, x, s_tab);
+        if (old) flips += __popc((old[i] & m) ^ x);
+        if (copy_to) copy_to[i] = x;
+    }
+    s_reg[t] = reg;
+    s_cnt[t] = flips;
+    __syncthreads();
+    uint32_t X = gf_xpow(32ull * (unsigned long long)c);
+    for (int s = 1; s < RK_LANES; s <<= 1) {
+        if ((t & (2 * s - 1)) == 0) {
+            s_reg[t] = gf_mulmod(s_reg[t], X) ^ s_reg[t + s];
+            s_cnt[t] += s_cnt[t + s];
+        }
+        X = gf_mulmod(X, X);
+        __syncthreads();
+    }
+    if (flips_out) *flips_out = s_cnt[0];
+    return s_reg[0] ^ gf_mulmod(0xFFFFFFFFu, gf_xpow(32ull * (unsigned long long)nw)) ^ 0xFFFFFFFFu;
+}
+
+/*
+ * Bob, after the decode: verification on the device.  Per block: CRC-32 of the decoded key bits against Alice's, the number of bits the
+ * decode flipped, and the verified key words (tail masked) in a compact [n][Wk] array -- the host receives {status, flips,
+ * iterations, crc} and the words, and touches nothing per bit.  A block that failed gets its ORIGINAL words back (key untouched).
+ */
+__global__ __launch_bounds__(RK_LANES) void rk_verify(const uint32_t *__restrict__ out, const uint32_t *__restrict__ key, const int *__restrict__ key_bits,
+                                                      const uint32_t *__restrict__ crc_want, const int *__restrict__ ok, const int *__restrict__ iters,
+                                                      uint32_t *__restrict__ res_keys, int *__restrict__ res, int n, int Wk, int Wn)
+{
+    __shared__ uint32_t s_tab[256], s_reg[RK_LANES];
+    __shared__ int s_cnt[RK_LANES];
+    const int b = (int)blockIdx.x;
+    const int kb = key_bits[b], nw = (kb + 31) / 32;
+    int flips = 0;
+    const uint32_t crc = rk_block_crc(out + (size_t)b * Wn, kb, key + (size_t)b * Wk, res_keys + (size_t)b * Wk, &flips, s_tab, s_reg, s_cnt);
+    const bool good = ok[b] && crc == crc_want[b];
+    if (!good)      /* uniform per workgroup */
+        for (int i = (int)threadIdx.x; i < nw; i += RK_LANES) res_keys[(size_t)b * Wk + i] = key[(size_t)b * Wk + i];
+    if (threadIdx.x == 0) {
+        res[b] = good ? QLDPC_OK : QLDPC_EDECODE;
+        res[n + b] = good ? flips : 0;
+        res[2 * n + b] = iters[b];
+        res[3 * n + b] = (int)crc;
+    }
+}
+
+/* Alice: CRC-32 of every key as it lies on the device (information words [n][Wk]) */
+__global__ __launch_bounds__(RK_LANES) void rk_crc(const uint32_t *__restrict__ key, const int *__restrict__ key_bits, uint32_t *__restrict__ crc_out, int Wk)
+{
+    __shared__ uint32_t s_tab[256], s_reg[RK_LANES];
+    __shared__ int s_cnt[RK_LANES];
+    const int b = (int)blockIdx.x;
+    const uint32_t crc = rk_block_crc(key + (size_t)b * Wk, key_bits[b], nullptr, nullptr, nullptr, s_tab, s_reg, s_cnt);
+    if (threadIdx.x == 0) crc_out[b] = crc;
+}
+
 extern "C" void qldpc_recon_cfg_default(qldpc_recon_cfg *c)
 {
     if (!c) return;
@@ -106,6 +259,7 @@ extern "C" void qldpc_recon_cfg_default(qldpc_recon_cfg *c)
     c->rate_gap = 0.0f;             /* 0 = by rule: 0.03 for SPA, 0.05 for the min-sum family */
     c->puncture = 1;
     c->preload = 0;
+    c->peg_depth = 0;
 }
 
 /*
@@ -179,11 +333,15 @@ static void entry_free(recon_entry &e)
     qldpc_decoder_free(e.dec);
     qldpc_encoder_free(e.enc);
     qldpc_code_free(e.code);
-    (void)hipFree(e.d_cls); (void)hipFree(e.d_key); (void)hipFree(e.d_disc); (void)hipFree(e.d_bits); (void)hipFree(e.d_erase); (void)hipFree(e.d_out);
-    (void)hipFree(e.d_mag); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok); (void)hipFree(e.d_nch); (void)hipFree(e.d_np);
-    (void)hipFree(e.d_in); (void)hipFree(e.d_res);
-    if (e.h_in) (void)hipHostFree(e.h_in);
-    if (e.h_res) (void)hipHostFree(e.h_res);
+    (void)hipFree(e.d_cls); (void)hipFree(e.d_out); (void)hipFree(e.d_iters); (void)hipFree(e.d_ok);
+    for (auto &st : e.set) {
+        (void)hipFree(st.d_in); (void)hipFree(st.d_res); (void)hipFree(st.d_bits); (void)hipFree(st.d_erase);
+        if (st.h_in) (void)hipHostFree(st.h_in);
+        if (st.h_res) (void)hipHostFree(st.h_res);
+        if (st.ev_in) (void)hipEventDestroy(st.ev_in);
+        if (st.ev_out) (void)hipEventDestroy(st.ev_out);
+        if (st.ev_done) (void)hipEventDestroy(st.ev_done);
+    }
 }
 
 extern "C" void qldpc_recon_free(qldpc_recon *r)
@@ -191,6 +349,10 @@ extern "C" void qldpc_recon_free(qldpc_recon *r)
     if (!r) return;
     (void)hipSetDevice(r->cfg.device);
     for (auto &e : r->cache) entry_free(e);
+    for (auto &l : r->lane) {
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.copy) (void)hipStreamDestroy(l.copy);
+    }
     delete r;
 }
 
@@ -207,6 +369,14 @@ static void code_dims(const qldpc_recon_cfg &c, int key_bits, double R, int *K, 
 }
 
 static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out);
+static void cache_trim(qldpc_recon *r)
+{
+    if (r->cache.size() <= r->keep) return;
+    (void)hipDeviceSynchronize();
+    while (r->cache.size() > r->keep) { entry_free(r->cache.back()); r->cache.pop_back(); }
+}
+#define RECON_IN_SCALARS 4      /* |LLR|, block length, punctured, Alice's CRC */
+#define RECON_RES_SCALARS 4     /* status, bits flipped, iterations, CRC found */
 
 extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
 {
@@ -215,7 +385,7 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     if (!cfg) return QLDPC_EINVAL;
     if (cfg->n_rates < 1 || cfg->n_rates > 8 || cfg->key_quantum < 32 || (cfg->key_quantum & 31) || cfg->max_blocks < 1 || cfg->n_ite < 1 ||
         !(cfg->efficiency > 0.0f) || cfg->mother_step < 0 || (cfg->mother_step & 31) || (cfg->mother_step > 0 && cfg->mother_max < cfg->mother_step) ||
-        !(cfg->rate_gap >= 0.0f && cfg->rate_gap < 0.5f) || cfg->reserved[0] || cfg->reserved[1]) {
+        !(cfg->rate_gap >= 0.0f && cfg->rate_gap < 0.5f) || cfg->peg_depth < 0 || cfg->peg_depth > 4 || cfg->reserved[0]) {
         qldpc_set_error("recon_create: bad configuration");
         return QLDPC_EINVAL;
     }
@@ -231,10 +401,20 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     const size_t mothers = cfg->mother_step > 0 ? (size_t)(cfg->mother_max / cfg->mother_step) * (size_t)cfg->n_rates : 0;
     r->keep = mothers + 6;
     r->created = 0;
+    r->profiling = 0;
+    memset(r->lane, 0, sizeof(r->lane));
+    if (hipSetDevice(cfg->device) != hipSuccess) { delete r; return QLDPC_EHIP; }
+    /* the session's own streams: nothing of it runs on the null stream, so a second session or other work on the device does not
+     * serialise behind it */
+    for (auto &l : r->lane)
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&l.copy, hipStreamNonBlocking) != hipSuccess) {
+            qldpc_set_error("recon_create: hipStreamCreate failed");
+            qldpc_recon_free(r);
+            return QLDPC_EHIP;
+        }
     if (cfg->preload && mothers) {
         /* every (mother size, table rate) pair now: code, encoder, decoder and staging buffers, so that no block of up to mother_max
          * bits builds a code or allocates device memory later (the daemon calls this from ldpc_init) */
-        if (hipSetDevice(cfg->device) != hipSuccess) { delete r; return QLDPC_EHIP; }
         for (int k = cfg->mother_step; k <= cfg->mother_max; k += cfg->mother_step)
             for (int i = 0; i < cfg->n_rates; i++) {
                 int K, M;
@@ -254,6 +434,7 @@ extern "C" long qldpc_recon_entries_created(const qldpc_recon *r) { return r ? r
 extern "C" int qldpc_recon_profile_enable(qldpc_recon *r, int on)
 {
     if (!r) return QLDPC_EINVAL;
+    r->profiling = on;
     for (auto &e : r->cache) { qldpc_profile_enable(e.dec, on); if (on) qldpc_profile_clear(e.dec); }
     return QLDPC_OK;
 }
@@ -340,7 +521,7 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     memset(&e, 0, sizeof(e));
     e.K = K; e.M = M;
     const int N = K + M, Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32, B = r->cfg.max_blocks;
-    int rc = qldpc_code_ira(N, K, 0.125f, 11, 3, r->cfg.seed, &e.code);
+    int rc = r->cfg.peg_depth > 0 ? qldpc_code_ira_peg(N, K, 0.125f, 11, 3, r->cfg.peg_depth, r->cfg.seed, &e.code) : qldpc_code_ira(N, K, 0.125f, 11, 3, r->cfg.seed, &e.code);
     if (!rc) rc = qldpc_encoder_create(e.code, "IRA", r->cfg.device, &e.enc);
     if (!rc) {
         qldpc_decoder_cfg dc;
@@ -352,28 +533,28 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     }
     auto alloc = [&](void **ptr, size_t bytes) { if (!rc && hipMalloc(ptr, bytes) != hipSuccess) rc = QLDPC_ENOMEM; };
     alloc((void **)&e.d_cls, (size_t)N);
-    alloc((void **)&e.d_key, sizeof(uint32_t) * (size_t)B * Wk);
-    alloc((void **)&e.d_disc, sizeof(uint32_t) * (size_t)B * Wm);
-    alloc((void **)&e.d_bits, sizeof(uint32_t) * (size_t)B * Wn);
-    alloc((void **)&e.d_erase, sizeof(uint32_t) * (size_t)B * Wn);
     alloc((void **)&e.d_out, sizeof(uint32_t) * (size_t)B * Wn);
-    alloc((void **)&e.d_mag, sizeof(float) * (size_t)B);
     alloc((void **)&e.d_iters, sizeof(int) * (size_t)B);
     alloc((void **)&e.d_ok, sizeof(int) * (size_t)B);
-    alloc((void **)&e.d_nch, sizeof(int) * (size_t)B);
-    alloc((void **)&e.d_np, sizeof(int) * (size_t)B);
-    alloc((void **)&e.d_in, sizeof(uint32_t) * (size_t)B * (Wk + Wm + 3));
-    alloc((void **)&e.d_res, sizeof(uint32_t) * (size_t)B * (Wn + 2));
-    if (!rc && hipHostMalloc((void **)&e.h_in, sizeof(uint32_t) * (size_t)B * (Wk + Wm + 3)) != hipSuccess) rc = QLDPC_ENOMEM;
-    if (!rc && hipHostMalloc((void **)&e.h_res, sizeof(uint32_t) * (size_t)B * (Wn + 2)) != hipSuccess) rc = QLDPC_ENOMEM;
+    for (auto &st : e.set) {
+        const size_t in_words = (size_t)B * (Wk + Wm + RECON_IN_SCALARS), res_words = (size_t)B * (Wk + RECON_RES_SCALARS);
+        alloc((void **)&st.d_in, sizeof(uint32_t) * in_words);
+        alloc((void **)&st.d_res, sizeof(uint32_t) * std::max(res_words, (size_t)B * (Wm + 1)));      /* Alice's side: disclosed parity [n][Wm] | CRC [n] */
+        alloc((void **)&st.d_bits, sizeof(uint32_t) * (size_t)B * Wn);
+        alloc((void **)&st.d_erase, sizeof(uint32_t) * (size_t)B * Wn);
+        if (!rc && hipHostMalloc((void **)&st.h_in, sizeof(uint32_t) * in_words) != hipSuccess) rc = QLDPC_ENOMEM;
+        if (!rc && hipHostMalloc((void **)&st.h_res, sizeof(uint32_t) * std::max(res_words, (size_t)B * (Wm + 1))) != hipSuccess) rc = QLDPC_ENOMEM;
+        if (!rc && (hipEventCreateWithFlags(&st.ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_out, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&st.ev_done, hipEventDisableTiming) != hipSuccess)) rc = QLDPC_EHIP;
+    }
     if (!rc) {
         std::vector<uint8_t> cls((size_t)N, (uint8_t)QLDPC_VN_PINNED);       /* parity VNs are disclosed; key VNs past a block's length are pinned per frame */
         for (int i = 0; i < K; i++) cls[(size_t)i] = (uint8_t)QLDPC_VN_CHANNEL;
         if (hipMemcpy(e.d_cls, cls.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) rc = QLDPC_EHIP;
     }
     if (rc) { entry_free(e); return rc; }
-    while (r->cache.size() >= r->keep) { entry_free(r->cache.back()); r->cache.pop_back(); }
-    r->cache.push_front(e);
+    if (r->profiling) qldpc_profile_enable(e.dec, 1);
+    r->cache.push_front(e);      /* the cache is trimmed to `keep` entries at the end of the call (cache_trim): nothing in use is evicted */
     r->created++;
     *out = &r->cache.front();
     return QLDPC_OK;
@@ -403,44 +584,249 @@ extern "C" int qldpc_recon_check_header(const qldpc_recon *r, const qldpc_recon_
     return check_msg(r, msg, key_bits);
 }
 
-/* blocks of ONE entry (same K, M): one encoder launch.  parity[i] receives ceil((M - n_punct) / 32) words. */
-static int encode_group(qldpc_recon *r, int n, const uint32_t *const *key, const int *key_bits, qldpc_recon_msg *const *msgs, uint32_t *const *parity)
+extern "C" int qldpc_recon_parity_words(const qldpc_recon_msg *msg) { return msg ? (int)((msg->code_m - msg->n_punct + 31) / 32) : QLDPC_EINVAL; }
+extern "C" int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg) { return msg ? (int)(msg->code_m - msg->n_punct) + 32 : QLDPC_EINVAL; }
+
+/* ------------------------------------------------------------------ the pipeline ------------------------------------------------
+ *
+ * A call brings blocks of any mix of codes.  Blocks of one code (entry) form batches of up to max_blocks frames = jobs; the jobs of
+ * one entry go to one lane (an entry has one decoder), the entries of a call are spread over up to RECON_LANES lanes, and every
+ * lane is a host worker with its own compute and copy stream:
+ *
+ *     copy stream     H2D(j) assemble(j) | H2D(j+1) assemble(j+1) | D2H(j)            | H2D(j+2) ...
+ *     compute stream                     | load(j) BP iterations(j) fetch verify(j)   | load(j+1) ...
+ *     host            stage(j) stage(j+1)  ... polls the early-exit mailbox of j ...    results(j-1) stage(j+2)
+ *
+ * so the rate groups of a stream of epochs decode side by side (their launches fill each other's tails), and within a lane the
+ * staging and the copies of the neighbouring batches hide behind the decode.  Nothing runs on the null stream.
+ */
+struct recon_job {
+    recon_entry *e;
+    std::vector<int> idx;       /* the job's blocks in the caller's arrays */
+    stage_set *st;
+    bool any_punct;
+};
+
+struct recon_call {
+    bool bob;
+    int n;
+    const int *key_bits;
+    /* Bob */
+    uint32_t *const *key; const float *qber; const qldpc_recon_msg *msgs; const uint32_t *const *parity; int *status, *corrected, *iterations;
+    /* Alice */
+    const uint32_t *const *akey; qldpc_recon_msg *amsgs; uint32_t *const *aparity;
+};
+
+struct lane_run {
+    qldpc_recon *r;
+    recon_lane *lane;
+    const recon_call *call;
+    std::vector<recon_job> jobs;
+    int rc;
+    std::string err;
+};
+
+static int job_stage(lane_run *L, recon_job &j, hipStream_t cs)
 {
-    const int K = (int)msgs[0]->code_k, M = (int)msgs[0]->code_m, N = K + M;
+    recon_entry *e = j.e;
+    const recon_call &c = *L->call;
+    const int n = (int)j.idx.size(), K = e->K, M = e->M, N = K + M;
+    const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
+    stage_set *st = &e->set[e->next_set];
+    e->next_set ^= 1;
+    j.st = st;
+    j.any_punct = false;
+    uint32_t *h_keys = st->h_in, *h_disc = h_keys + (size_t)n * Wk;
+    float *h_mag = reinterpret_cast<float *>(h_disc + (size_t)n * Wm);
+    int *h_nch = reinterpret_cast<int *>(h_mag + n), *h_np = h_nch + n;
+    uint32_t *h_crc = reinterpret_cast<uint32_t *>(h_np + n);
+    for (int t = 0; t < n; t++) {
+        const int i = j.idx[(size_t)t], kb = c.key_bits[i], Wkey = (kb + 31) / 32;
+        uint32_t *f = h_keys + (size_t)t * Wk;
+        if (c.bob) {
+            /* only the words the kernels read are copied: rk_assemble masks the tail and never looks past the block's length */
+            memcpy(f, c.key[i], sizeof(uint32_t) * (size_t)Wkey);
+            h_np[t] = (int)c.msgs[i].n_punct;
+            memcpy(h_disc + (size_t)t * Wm, c.parity[i], sizeof(uint32_t) * (size_t)((M - h_np[t] + 31) / 32));
+            h_mag[t] = qldpc_bsc_llr(clamp_qber(c.qber[i]));
+            h_crc[t] = c.msgs[i].crc32;
+        } else {
+            /* information word of the mother code: the key, then zeros (shortened positions) */
+            memcpy(f, c.akey[i], sizeof(uint32_t) * (size_t)Wkey);
+            if (kb & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (kb & 31));
+            memset(f + Wkey, 0, sizeof(uint32_t) * (size_t)(Wk - Wkey));
+            h_np[t] = (int)c.amsgs[i].n_punct;
+            h_mag[t] = 0.0f; h_crc[t] = 0;
+        }
+        h_nch[t] = kb;
+        j.any_punct = j.any_punct || h_np[t] != 0;
+    }
+    const size_t in_words = (size_t)n * (Wk + Wm + RECON_IN_SCALARS);
+    HIPCHK(hipMemcpyAsync(st->d_in, st->h_in, sizeof(uint32_t) * in_words, hipMemcpyHostToDevice, cs));
+    if (c.bob) {
+        uint32_t *d_keys = st->d_in, *d_disc = d_keys + (size_t)n * Wk;
+        int *d_nch = reinterpret_cast<int *>(d_disc + (size_t)n * Wm + n), *d_np = d_nch + n;
+        hipLaunchKernelGGL(rk_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n), dim3(256), 0, cs, d_keys, d_disc, d_nch, d_np, st->d_bits, st->d_erase, Wk, Wn, Wm, M);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(st->ev_in, cs));
+    return QLDPC_OK;
+}
+
+static int job_launch(lane_run *L, recon_job &j, hipStream_t cs)
+{
+    recon_entry *e = j.e;
+    stage_set *st = j.st;
+    hipStream_t s = L->lane->stream;
+    const int n = (int)j.idx.size(), K = e->K, M = e->M, N = K + M;
     const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
     int rc;
-    recon_entry *e;
-    if ((rc = get_entry(r, K, M, &e))) return rc;
-    std::vector<uint32_t> info((size_t)n * Wk, 0u), disc((size_t)n * Wm);
-    std::vector<int> np((size_t)n);
-    for (int t = 0; t < n; t++) {
-        const int kb = key_bits[t], Wkey = (kb + 31) / 32;
-        uint32_t *f = info.data() + (size_t)t * Wk;
-        memcpy(f, key[t], sizeof(uint32_t) * (size_t)Wkey);
-        if (kb & 31) f[Wkey - 1] &= 0xFFFFFFFFu << (32 - (kb & 31));
-        np[(size_t)t] = (int)msgs[t]->n_punct;
+    uint32_t *d_keys = st->d_in, *d_disc = d_keys + (size_t)n * Wk;
+    float *d_mag = reinterpret_cast<float *>(d_disc + (size_t)n * Wm);
+    int *d_nch = reinterpret_cast<int *>(d_mag + n), *d_np = d_nch + n;
+    uint32_t *d_crc = reinterpret_cast<uint32_t *>(d_np + n);
+    if (cs != s) HIPCHK(hipStreamWaitEvent(s, st->ev_in, 0));
+    size_t res_words;
+    if (L->call->bob) {
+        if ((rc = qldpc_decoder_set_stream(e->dec, (void *)s))) return rc;
+        if ((rc = qldpc_load_bits_short_dev(e->dec, st->d_bits, d_mag, e->d_cls, d_nch, n))) return rc;
+        if (j.any_punct && (rc = qldpc_load_erasures_dev(e->dec, st->d_erase, n))) return rc;
+        if ((rc = qldpc_run(e->dec))) return rc;      /* the host polls the decoder's early-exit mailbox in here */
+        if ((rc = qldpc_fetch_packed_dev(e->dec, e->d_out))) return rc;
+        if ((rc = qldpc_fetch_status_dev(e->dec, e->d_iters, e->d_ok))) return rc;
+        uint32_t *res_keys = st->d_res;
+        int *res = reinterpret_cast<int *>(res_keys + (size_t)n * Wk);
+        hipLaunchKernelGGL(rk_verify, dim3((unsigned)n), dim3(RK_LANES), 0, s, e->d_out, d_keys, d_nch, d_crc, e->d_ok, e->d_iters, res_keys, res, n, Wk, Wn);
+        HIPCHK(hipGetLastError());
+        res_words = (size_t)n * (Wk + RECON_RES_SCALARS);
+    } else {
+        if ((rc = qldpc_encode_packed_dev(e->enc, d_keys, e->d_out, n, (void *)s))) return rc;
+        uint32_t *res_disc = st->d_res, *res_crc = res_disc + (size_t)n * Wm;
+        hipLaunchKernelGGL(rk_disclose, dim3((unsigned)((Wm + 255) / 256), (unsigned)n), dim3(256), 0, s, e->d_out, d_np, res_disc, Wk, Wn, Wm, M);
+        hipLaunchKernelGGL(rk_crc, dim3((unsigned)n), dim3(RK_LANES), 0, s, d_keys, d_nch, res_crc, Wk);
+        HIPCHK(hipGetLastError());
+        res_words = (size_t)n * (Wm + 1);
     }
-    HIPCHK(hipMemcpy(e->d_key, info.data(), sizeof(uint32_t) * info.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_np, np.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
-    if ((rc = qldpc_encode_packed_dev(e->enc, e->d_key, e->d_out, n, nullptr))) return rc;
-    hipLaunchKernelGGL(rk_disclose, dim3((unsigned)((Wm + 255) / 256), (unsigned)n), dim3(256), 0, 0, e->d_out, e->d_np, e->d_disc, Wk, Wn, Wm, M);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(disc.data(), e->d_disc, sizeof(uint32_t) * disc.size(), hipMemcpyDeviceToHost));
-    for (int t = 0; t < n; t++) {
-        const int Wd = (M - np[(size_t)t] + 31) / 32;
-        memcpy(parity[t], disc.data() + (size_t)t * Wm, sizeof(uint32_t) * (size_t)Wd);
-        msgs[t]->crc32 = qldpc_crc32_words(key[t], key_bits[t]);
+    if (cs != s) {
+        HIPCHK(hipEventRecord(st->ev_out, s));
+        HIPCHK(hipStreamWaitEvent(cs, st->ev_out, 0));
+    }
+    HIPCHK(hipMemcpyAsync(st->h_res, st->d_res, sizeof(uint32_t) * res_words, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipEventRecord(st->ev_done, cs));
+    return QLDPC_OK;
+}
+
+static int job_finish(lane_run *L, recon_job &j)
+{
+    recon_entry *e = j.e;
+    stage_set *st = j.st;
+    const recon_call &c = *L->call;
+    const int n = (int)j.idx.size(), K = e->K, M = e->M;
+    const int Wk = K / 32, Wm = (M + 31) / 32;
+    HIPCHK(hipEventSynchronize(st->ev_done));
+    if (c.bob) {
+        const uint32_t *keys = st->h_res;
+        const int *res = reinterpret_cast<const int *>(keys + (size_t)n * Wk);
+        for (int t = 0; t < n; t++) {
+            const int i = j.idx[(size_t)t], Wkey = (c.key_bits[i] + 31) / 32;
+            c.status[i] = res[t];
+            if (c.corrected) c.corrected[i] = res[n + t];
+            if (c.iterations) c.iterations[i] = res[2 * n + t];
+            if (res[t] == QLDPC_OK) memcpy(c.key[i], keys + (size_t)t * Wk, sizeof(uint32_t) * (size_t)Wkey);      /* a failed block keeps its key untouched */
+        }
+    } else {
+        const uint32_t *disc = st->h_res, *crc = disc + (size_t)n * Wm;
+        for (int t = 0; t < n; t++) {
+            const int i = j.idx[(size_t)t];
+            memcpy(c.aparity[i], disc + (size_t)t * Wm, sizeof(uint32_t) * (size_t)qldpc_recon_parity_words(&c.amsgs[i]));
+            c.amsgs[i].crc32 = crc[t];
+        }
     }
     return QLDPC_OK;
 }
 
-extern "C" int qldpc_recon_parity_words(const qldpc_recon_msg *msg) { return msg ? (int)((msg->code_m - msg->n_punct + 31) / 32) : QLDPC_EINVAL; }
-extern "C" int qldpc_recon_leaked_bits(const qldpc_recon_msg *msg) { return msg ? (int)(msg->code_m - msg->n_punct) + 32 : QLDPC_EINVAL; }
+static void lane_main(lane_run *L)
+{
+    int rc = QLDPC_OK;
+    if (hipSetDevice(L->r->cfg.device) != hipSuccess) { L->rc = QLDPC_EHIP; L->err = "hipSetDevice failed"; return; }
+    const size_t nj = L->jobs.size();
+    /* one job: everything in order on the compute stream (no cross-stream hand-offs on the daemon's one-block path) */
+    hipStream_t cs = nj > 1 ? L->lane->copy : L->lane->stream;
+    size_t launched = 0, finished = 0;
+    rc = job_stage(L, L->jobs[0], cs);
+    for (size_t i = 0; i < nj && !rc; i++) {
+        if (i + 1 < nj) rc = job_stage(L, L->jobs[i + 1], cs);
+        if (!rc) { rc = job_launch(L, L->jobs[i], cs); if (!rc) launched = i + 1; }
+        if (!rc && i > 0) { rc = job_finish(L, L->jobs[i - 1]); if (!rc) finished = i; }
+    }
+    for (size_t i = finished; i < launched && !rc; i++) rc = job_finish(L, L->jobs[i]);
+    if (rc) {
+        L->err = qldpc_last_error();
+        (void)hipStreamSynchronize(L->lane->stream);
+        (void)hipStreamSynchronize(L->lane->copy);
+    }
+    L->rc = rc;
+}
+
+/* groups: blocks by code.  Entries are looked up / built here, in the calling thread; jobs of one entry stay on one lane, the
+ * entries are dealt onto the lanes largest first. */
+static int run_call(qldpc_recon *r, const recon_call &call, const std::vector<char> &skip)
+{
+    int rc;
+    HIPCHK(hipSetDevice(r->cfg.device));
+    struct group { recon_entry *e; std::vector<int> idx; double cost; };
+    std::vector<group> groups;
+    const int n = call.n;
+    std::vector<char> taken(skip);
+    for (int i = 0; i < n; i++) {
+        if (taken[(size_t)i]) continue;
+        const qldpc_recon_msg &mi = call.bob ? call.msgs[i] : call.amsgs[i];
+        group g;
+        for (int j = i; j < n; j++) {
+            const qldpc_recon_msg &mj = call.bob ? call.msgs[j] : call.amsgs[j];
+            if (!taken[(size_t)j] && mj.code_k == mi.code_k && mj.code_m == mi.code_m) { g.idx.push_back(j); taken[(size_t)j] = 1; }
+        }
+        if ((rc = get_entry(r, (int)mi.code_k, (int)mi.code_m, &g.e))) { cache_trim(r); return rc; }
+        g.cost = (double)g.idx.size() * (double)(mi.code_k + mi.code_m);
+        groups.push_back(std::move(g));
+    }
+    if (groups.empty()) return QLDPC_OK;
+    int n_lanes = RECON_LANES;
+    if (const char *env = getenv("QLDPC_RECON_LANES")) n_lanes = std::max(1, std::min(RECON_LANES, atoi(env)));
+    n_lanes = std::min(n_lanes, (int)groups.size());
+    std::sort(groups.begin(), groups.end(), [](const group &a, const group &b) { return a.cost > b.cost; });
+    std::vector<lane_run> runs((size_t)n_lanes);
+    std::vector<double> load((size_t)n_lanes, 0.0);
+    for (int l = 0; l < n_lanes; l++) { runs[(size_t)l].r = r; runs[(size_t)l].lane = &r->lane[l]; runs[(size_t)l].call = &call; runs[(size_t)l].rc = QLDPC_OK; }
+    const size_t B = (size_t)r->cfg.max_blocks;
+    for (auto &g : groups) {
+        const size_t l = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[l] += g.cost;
+        for (size_t at = 0; at < g.idx.size(); at += B) {
+            recon_job j;
+            j.e = g.e; j.st = nullptr; j.any_punct = false;
+            j.idx.assign(g.idx.begin() + (long)at, g.idx.begin() + (long)std::min(g.idx.size(), at + B));
+            runs[l].jobs.push_back(std::move(j));
+        }
+    }
+    if (n_lanes == 1) lane_main(&runs[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int l = 1; l < n_lanes; l++) th.emplace_back(lane_main, &runs[(size_t)l]);
+        lane_main(&runs[0]);
+        for (auto &t : th) t.join();
+    }
+    rc = QLDPC_OK;
+    for (auto &L : runs)
+        if (L.rc && !rc) { rc = L.rc; qldpc_set_error("%s", L.err.c_str()); }
+    cache_trim(r);
+    return rc;
+}
 
 /*
  * Alice's side for many blocks at once: plans every block (msgs[i] is filled as by qldpc_recon_encode), groups the blocks by
  * code and encodes each group in launches of up to max_blocks frames.  parity_words[i] receives qldpc_recon_parity_words(&msgs[i])
- * words (parity_cap[i] are available).
+ * words (parity_cap[i] are available).  The key's CRC-32 is computed on the device as well (rk_crc).
  */
 extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *const *key_words, const int *key_bits, const float *qber,
                                          qldpc_recon_msg *msgs, uint32_t *const *parity_words, const int *parity_cap)
@@ -452,24 +838,10 @@ extern "C" int qldpc_recon_encode_blocks(qldpc_recon *r, int n, const uint32_t *
         if ((rc = qldpc_recon_plan(r, key_bits[i], qber[i], &msgs[i]))) return rc;
         if (parity_cap[i] < qldpc_recon_parity_words(&msgs[i])) { qldpc_set_error("recon_encode_blocks: parity buffer %d holds %d words, need %d", i, parity_cap[i], qldpc_recon_parity_words(&msgs[i])); return QLDPC_ESIZE; }
     }
-    HIPCHK(hipSetDevice(r->cfg.device));
-    std::vector<char> taken((size_t)n, 0);
-    for (int i = 0; i < n; i++) {
-        if (taken[(size_t)i]) continue;
-        std::vector<int> idx;
-        for (int j = i; j < n; j++)
-            if (!taken[(size_t)j] && msgs[j].code_k == msgs[i].code_k && msgs[j].code_m == msgs[i].code_m) { idx.push_back(j); taken[(size_t)j] = 1; }
-        for (size_t at = 0; at < idx.size(); at += (size_t)r->cfg.max_blocks) {
-            const int m = (int)std::min(idx.size() - at, (size_t)r->cfg.max_blocks);
-            std::vector<const uint32_t *> k((size_t)m);
-            std::vector<uint32_t *> p((size_t)m);
-            std::vector<qldpc_recon_msg *> mm((size_t)m);
-            std::vector<int> kb((size_t)m);
-            for (int t = 0; t < m; t++) { const int j = idx[at + (size_t)t]; k[(size_t)t] = key_words[j]; p[(size_t)t] = parity_words[j]; mm[(size_t)t] = &msgs[j]; kb[(size_t)t] = key_bits[j]; }
-            if ((rc = encode_group(r, m, k.data(), kb.data(), mm.data(), p.data()))) return rc;
-        }
-    }
-    return QLDPC_OK;
+    recon_call c;
+    memset(&c, 0, sizeof(c));
+    c.bob = false; c.n = n; c.key_bits = key_bits; c.akey = key_words; c.amsgs = msgs; c.aparity = parity_words;
+    return run_call(r, c, std::vector<char>((size_t)n, 0));
 }
 
 extern "C" int qldpc_recon_encode(qldpc_recon *r, const uint32_t *key_words, int key_bits, float qber, qldpc_recon_msg *msg, uint32_t *parity_words, int cap)
@@ -491,79 +863,17 @@ extern "C" int qldpc_recon_encode_planned(qldpc_recon *r, const uint32_t *key_wo
     int rc;
     if ((rc = check_msg(r, msg, key_bits))) return rc;
     if (cap < qldpc_recon_parity_words(msg)) { qldpc_set_error("recon_encode_planned: parity buffer holds %d words, need %d", cap, qldpc_recon_parity_words(msg)); return QLDPC_ESIZE; }
-    HIPCHK(hipSetDevice(r->cfg.device));
-    return encode_group(r, 1, &key_words, &key_bits, &msg, &parity_words);
-}
-
-/* blocks of ONE entry (same K, M), possibly of different length and puncturing: one launch.  key[i] is decoded in place. */
-static int decode_group(qldpc_recon *r, int n, uint32_t *const *key, const int *key_bits, const float *qber, const qldpc_recon_msg *const *msgs,
-                        const uint32_t *const *parity, int *const *status, int *const *corrected, int *const *iterations)
-{
-    const int K = (int)msgs[0]->code_k, M = (int)msgs[0]->code_m, N = K + M;
-    const int Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32;
-    int rc;
-    HIPCHK(hipSetDevice(r->cfg.device));
-    recon_entry *e;
-    if ((rc = get_entry(r, K, M, &e))) return rc;
-    /* staging: everything Bob's side needs, packed into the entry's pinned block -> one copy; the results come back the same way */
-    uint32_t *h_keys = e->h_in, *h_disc = h_keys + (size_t)n * Wk;
-    float *h_mag = reinterpret_cast<float *>(h_disc + (size_t)n * Wm);
-    int *h_nch = reinterpret_cast<int *>(h_mag + n), *h_np = h_nch + n;
-    uint32_t *d_keys = e->d_in, *d_disc = d_keys + (size_t)n * Wk;
-    float *d_mag = reinterpret_cast<float *>(d_disc + (size_t)n * Wm);
-    int *d_nch = reinterpret_cast<int *>(d_mag + n), *d_np = d_nch + n;
-    memset(h_keys, 0, sizeof(uint32_t) * (size_t)n * (Wk + Wm));
-    bool any_punct = false;
-    for (int i = 0; i < n; i++) {
-        const int Wkey = (key_bits[i] + 31) / 32;
-        memcpy(h_keys + (size_t)i * Wk, key[i], sizeof(uint32_t) * (size_t)Wkey);
-        h_np[i] = (int)msgs[i]->n_punct;
-        h_nch[i] = key_bits[i];
-        any_punct = any_punct || h_np[i] != 0;
-        memcpy(h_disc + (size_t)i * Wm, parity[i], sizeof(uint32_t) * (size_t)((M - h_np[i] + 31) / 32));
-        h_mag[i] = qldpc_bsc_llr(clamp_qber(qber[i]));
-    }
-    HIPCHK(hipMemcpyAsync(e->d_in, e->h_in, sizeof(uint32_t) * (size_t)n * (Wk + Wm + 3), hipMemcpyHostToDevice, 0));
-    hipLaunchKernelGGL(rk_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n), dim3(256), 0, 0, d_keys, d_disc, d_nch, d_np, e->d_bits, e->d_erase, Wk, Wn, Wm, M);
-    HIPCHK(hipGetLastError());
-    if ((rc = qldpc_load_bits_short_dev(e->dec, e->d_bits, d_mag, e->d_cls, d_nch, n))) return rc;
-    if (any_punct && (rc = qldpc_load_erasures_dev(e->dec, e->d_erase, n))) return rc;
-    if ((rc = qldpc_run(e->dec))) return rc;
-    uint32_t *d_outw = e->d_res;
-    int *d_it = reinterpret_cast<int *>(d_outw + (size_t)n * Wn), *d_okf = d_it + n;
-    if ((rc = qldpc_fetch_packed_dev(e->dec, d_outw))) return rc;
-    if ((rc = qldpc_fetch_status_dev(e->dec, d_it, d_okf))) return rc;
-    HIPCHK(hipMemcpyAsync(e->h_res, e->d_res, sizeof(uint32_t) * (size_t)n * (Wn + 2), hipMemcpyDeviceToHost, 0));
-    if ((rc = qldpc_sync(e->dec))) return rc;
-    const uint32_t *outw_p = e->h_res;
-    const int *it = reinterpret_cast<const int *>(outw_p + (size_t)n * Wn), *ok = it + n;
-    for (int i = 0; i < n; i++) {
-        const int kb = key_bits[i], Wkey = (kb + 31) / 32;
-        const uint32_t *o = outw_p + (size_t)i * Wn;
-        uint32_t *kw = key[i];
-        const bool good = ok[i] && qldpc_crc32_words(o, kb) == msgs[i]->crc32;
-        *status[i] = good ? QLDPC_OK : QLDPC_EDECODE;
-        if (iterations[i]) *iterations[i] = it[i];
-        int flips = 0;
-        if (good) {
-            for (int w = 0; w < Wkey; w++) {
-                uint32_t nw = o[w];
-                if (w == Wkey - 1 && (kb & 31)) nw &= 0xFFFFFFFFu << (32 - (kb & 31));
-                uint32_t old = kw[w];
-                if (w == Wkey - 1 && (kb & 31)) old &= 0xFFFFFFFFu << (32 - (kb & 31));
-                flips += __builtin_popcount(old ^ nw);
-                kw[w] = nw;
-            }
-        }
-        if (corrected[i]) *corrected[i] = flips;
-    }
-    return QLDPC_OK;
+    recon_call c;
+    memset(&c, 0, sizeof(c));
+    c.bob = false; c.n = 1; c.key_bits = &key_bits; c.akey = &key_words; c.amsgs = msg; c.aparity = &parity_words;
+    return run_call(r, c, std::vector<char>(1, 0));
 }
 
 /*
  * Blocks of any mix of lengths, rates and puncturing in one call ("let many blocks queue and decode in one
- * launch"): blocks are grouped by code (code_k, code_m) and every group goes through the decoder in launches of up to max_blocks
- * frames; within a group the blocks may differ in length (shortening per frame) and in efficiency (puncturing per frame).
+ * launch"): blocks are grouped by code (code_k, code_m), every group goes through its decoder in batches of up to max_blocks
+ * frames, and the groups of a call run side by side (the pipeline above); within a group the blocks may differ in length
+ * (shortening per frame) and in efficiency (puncturing per frame).  keys are decoded in place.
  * Every message is validated on its own: status[i] = QLDPC_OK | QLDPC_EDECODE | QLDPC_ESIZE (header does not match the block /
  * the local plan -- that block is not decoded, the others are).
  */
@@ -571,37 +881,19 @@ extern "C" int qldpc_recon_decode_blocks(qldpc_recon *r, int n, uint32_t *const 
                                          const qldpc_recon_msg *msgs, const uint32_t *const *parity_words, int *status, int *corrected, int *iterations)
 {
     if (!r || !key_words || !key_bits || !qber || !msgs || !parity_words || !status || n <= 0) return QLDPC_EINVAL;
-    int rc;
-    std::vector<char> taken((size_t)n, 0);
+    std::vector<char> skip((size_t)n, 0);
     for (int i = 0; i < n; i++) {
         if (!key_words[i] || !parity_words[i]) return QLDPC_EINVAL;
         status[i] = QLDPC_EDECODE;
         if (corrected) corrected[i] = 0;
         if (iterations) iterations[i] = 0;
-        if (check_msg(r, &msgs[i], key_bits[i]) || !(qber[i] >= 0.0f && qber[i] < 0.5f)) { status[i] = QLDPC_ESIZE; taken[(size_t)i] = 1; }
+        if (check_msg(r, &msgs[i], key_bits[i]) || !(qber[i] >= 0.0f && qber[i] < 0.5f)) { status[i] = QLDPC_ESIZE; skip[(size_t)i] = 1; }
     }
-    for (int i = 0; i < n; i++) {
-        if (taken[(size_t)i]) continue;
-        std::vector<int> idx;
-        for (int j = i; j < n; j++)
-            if (!taken[(size_t)j] && msgs[j].code_k == msgs[i].code_k && msgs[j].code_m == msgs[i].code_m) { idx.push_back(j); taken[(size_t)j] = 1; }
-        for (size_t at = 0; at < idx.size(); at += (size_t)r->cfg.max_blocks) {
-            const int m = (int)std::min(idx.size() - at, (size_t)r->cfg.max_blocks);
-            std::vector<uint32_t *> k((size_t)m);
-            std::vector<const uint32_t *> p((size_t)m);
-            std::vector<const qldpc_recon_msg *> mm((size_t)m);
-            std::vector<int> kb((size_t)m);
-            std::vector<float> qb((size_t)m);
-            std::vector<int *> st((size_t)m), co((size_t)m), itp((size_t)m);
-            for (int t = 0; t < m; t++) {
-                const int j = idx[at + (size_t)t];
-                k[(size_t)t] = key_words[j]; p[(size_t)t] = parity_words[j]; mm[(size_t)t] = &msgs[j]; kb[(size_t)t] = key_bits[j]; qb[(size_t)t] = qber[j];
-                st[(size_t)t] = &status[j]; co[(size_t)t] = corrected ? &corrected[j] : nullptr; itp[(size_t)t] = iterations ? &iterations[j] : nullptr;
-            }
-            if ((rc = decode_group(r, m, k.data(), kb.data(), qb.data(), mm.data(), p.data(), st.data(), co.data(), itp.data()))) return rc;
-        }
-    }
-    return QLDPC_OK;
+    recon_call c;
+    memset(&c, 0, sizeof(c));
+    c.bob = true; c.n = n; c.key_bits = key_bits; c.key = key_words; c.qber = qber; c.msgs = msgs; c.parity = parity_words;
+    c.status = status; c.corrected = corrected; c.iterations = iterations;
+    return run_call(r, c, skip);
 }
 
 /* n blocks of ONE length, contiguous arrays (the config-3 stream driver's call); parity_words rows are ceil(code_m / 32) words apart */

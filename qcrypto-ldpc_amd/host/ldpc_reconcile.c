@@ -21,11 +21,19 @@
 #include "subcomponents/processblock_mgmt.h"
 #include "definitions/proc_state.h"
 
-static qldpc_recon *g_recon = NULL;
+/* one engine per device (`-L D<n>`: blocks go round-robin over n devices by epoch, SURVEY.md section 8e "replicas only") */
+static qldpc_recon *g_recons[LDPC_MAX_DEVICES];
+static int g_devices = 1;
 static int ldpc_batchSize(void);
+static qldpc_recon *ldpc_engineFor(const ProcessBlock *pb) { return g_recons[ldpc_deviceOf(pb->startEpoch, g_devices)]; }
 
 /* ---- options: the daemon's -L letter (ecd2.c:26), with the environment as the fall-back for unmodified command lines ---------- */
-static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_margin = 0, g_opt_second = 1;
+static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_packet = -1, g_opt_margin = 0, g_opt_second = 1;
+#ifdef LDPC_TEST_HOOKS
+/* fault injection for the loopback tests (oracle/build_ref_ecd2.sh sets -DLDPC_TEST_HOOKS for the test binary only): a plugin built as
+ * INTEGRATION.md section 2 describes does not parse these letters and has none of the code below them */
+static int g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_noplan = 0, g_opt_badfrag = 0;
+#endif
 static int g_batch = -1, g_wait_ms = -1;
 
 static int ldpc_envInt(const char *name, int dflt)
@@ -48,11 +56,16 @@ int ldpc_parseOption(const char *optarg)
         case 'w': g_wait_ms = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_wait_ms < 0) return 1; break;
         case 'f': g_opt_fallback = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;
         case 'p': g_opt_max_packet = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_max_packet < 256) return 1; break;
-        case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* fault injection (tests): flip n disclosed parity bits */
-        case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* fault injection (tests): send every parity packet n more times */
+#ifdef LDPC_TEST_HOOKS
+        case 'x': g_opt_fault = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;      /* flip n disclosed parity bits */
+        case 'd': g_opt_dup = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;        /* send every parity packet n more times */
+        case 'y': g_opt_badhdr = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* claim another rate index in the header */
+        case 'n': g_opt_noplan = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* the initiator's plan comes back "no code for this QBER" */
+        case 'z': g_opt_badfrag = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;    /* fragment 1 claims a word offset that is off by n */
+#endif
+        case 'D': g_devices = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_devices < 1 || g_devices > LDPC_MAX_DEVICES) return 1; break;   /* blocks round-robin over n devices */
         case 'm': g_opt_margin = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_margin < 0 || g_opt_margin > 100) return 1; break;   /* plan for qber + n/10 sigma of its estimate */
         case 'r': g_opt_second = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* r0: no second round, a failed decode goes straight to cascade */
-        case 'y': g_opt_badhdr = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* fault injection (tests): claim another rate index in the header */
         default: return 1;
         }
         p = end;
@@ -81,9 +94,16 @@ int ldpc_selected(void) { return g_opt_select >= 0 ? g_opt_select : (getenv("ECD
 int ldpc_selectedFor(const ProcessBlock *pb)
 {
     qldpc_recon_msg msg;
+    int i, kept = 0;
     if (!ldpc_selected()) return 0;
-    if (!g_recon || pb->initialBits >= (1 << 16)) return 1;
-    return qldpc_recon_plan(g_recon, pb->initialBits, pb->localError, &msg) != QLDPC_EUNSUPPORTED;
+    if (!g_recons[0] || pb->initialBits >= (1 << 16)) return 1;
+    /* the length the initiator will plan on: workbits after helper_cleanupRevealedBits (helpers.c:31-69) = the bits of the block
+     * whose marker is clear.  Planning on initialBits could pick another mother size, whose gap from capacity differs, and choose
+     * LDPC for a block the initiator then cannot plan (it answers with a "no plan" header in that case, see ldpc_initiateAfterQber). */
+    for (i = 0; i < pb->initialBits; i++)
+        if (!(pb->testedBitsMarker[wordIndex(i)] & uint32AllZeroExceptAtN(i))) kept++;
+    if (kept < 32) return 0;
+    return qldpc_recon_plan(ldpc_engineFor(pb), kept, pb->localError, &msg) != QLDPC_EUNSUPPORTED;
 }
 int ldpc_gpuPrivAmp(void) { return g_opt_gpu_pa >= 0 ? g_opt_gpu_pa : (getenv("ECD2_GPU_PA") != NULL); }
 static int ldpc_maxPacketBytes(void)
@@ -97,25 +117,31 @@ static int ldpc_maxPacketBytes(void)
 int ldpc_init(int device)
 {
     qldpc_recon_cfg cfg;
-    if (g_recon) return 0;
-    qldpc_recon_cfg_default(&cfg);
-    cfg.device = device;
-    cfg.preload = 1;                   /* every mother code / encoder / decoder now: no construction, no device allocation per block */
-    cfg.max_blocks = ldpc_batchSize();
-    if (qldpc_recon_create(&cfg, &g_recon) != QLDPC_OK) {
-        fprintf(stderr, "ldpc_init: %s\n", qldpc_last_error());
-        return LDPC_ERR_ENGINE;
+    int d;
+    if (g_recons[0]) return 0;
+    for (d = 0; d < g_devices; d++) {
+        qldpc_recon_cfg_default(&cfg);
+        cfg.device = device + d;
+        cfg.preload = 1;                   /* every mother code / encoder / decoder now: no construction, no device allocation per block */
+        cfg.max_blocks = ldpc_batchSize();
+        if (qldpc_recon_create(&cfg, &g_recons[d]) != QLDPC_OK) {
+            fprintf(stderr, "ldpc_init: device %d: %s\n", device + d, qldpc_last_error());
+            ldpc_shutdown();
+            return LDPC_ERR_ENGINE;
+        }
     }
-    printf("ldpc: engine ready, %ld code / encoder / decoder sets built, up to %d blocks per decode call\n", qldpc_recon_entries_created(g_recon), cfg.max_blocks);
+    printf("ldpc: engine ready, %ld code / encoder / decoder sets built, up to %d blocks per decode call, %d device(s)\n", qldpc_recon_entries_created(g_recons[0]), cfg.max_blocks, g_devices);
     fflush(stdout);
     return 0;
 }
 
 void ldpc_shutdown(void)
 {
-    qldpc_recon_free(g_recon);
-    g_recon = NULL;
+    int d;
+    for (d = 0; d < LDPC_MAX_DEVICES; d++) { qldpc_recon_free(g_recons[d]); g_recons[d] = NULL; }
 }
+
+int ldpc_deviceForBlock(const ProcessBlock *pb) { return ldpc_deviceOf(pb->startEpoch, g_devices); }
 
 /* ---- data manager (definitions/algorithms/data_manager.h:28-32) ---------------------------- */
 
@@ -301,10 +327,13 @@ static int ldpc_sendParityPackets(ProcessBlock *pb, const qldpc_recon_msg *msg, 
         const unsigned int off = f * perPacket, words = (parityWords - off < perPacket) ? parityWords - off : perPacket;
         EcPktHdr_LdpcParity *h9;
         if ((errorCode = ldpc_createHeader((char **)&h9, SUBTYPE_LDPC_PARITY, sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE, pb))) break;
-        h9->rateIndex = msg->rate_index + (unsigned int)g_opt_badhdr; h9->keyBits = msg->key_bits; h9->codeK = msg->code_k; h9->codeM = msg->code_m;
+        h9->rateIndex = msg->rate_index; h9->keyBits = msg->key_bits; h9->codeK = msg->code_k; h9->codeM = msg->code_m;
         h9->crc32 = msg->crc32; h9->nPunct = msg->n_punct;
         h9->fragIndex = f; h9->fragCount = fragCount; h9->fragWordOffset = off;
-        memcpy(&h9[1], parity + off, words * WORD_SIZE);
+        if (words) memcpy(&h9[1], parity + off, words * WORD_SIZE);
+#ifdef LDPC_TEST_HOOKS
+        if (msg->rate_index != LDPC_NO_PLAN) h9->rateIndex += (unsigned int)g_opt_badhdr;
+        if (f == 1) h9->fragWordOffset += (unsigned int)g_opt_badfrag;
         {
             int d;
             for (d = 0; d < g_opt_dup && !errorCode; d++) {      /* tests only: the same packet again */
@@ -314,6 +343,7 @@ static int ldpc_sendParityPackets(ProcessBlock *pb, const qldpc_recon_msg *msg, 
                 errorCode = comms_insertSendPacket(copy, h9->base.totalLengthInBytes);
             }
         }
+#endif
         if (!errorCode) errorCode = comms_insertSendPacket((char *)h9, h9->base.totalLengthInBytes);
         else free2(h9);
     }
@@ -331,19 +361,38 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
     float qplan;
 
     qplan = ldpc_planQber(pb);
-    rc = qldpc_recon_plan(g_recon, pb->workbits, qplan, &msg);
+    rc = qldpc_recon_plan(ldpc_engineFor(pb), pb->workbits, qplan, &msg);
     if (rc == QLDPC_EUNSUPPORTED && qplan > pb->localError) {      /* the margin pushed the plan off the rate table: plan for the estimate itself */
         qplan = pb->localError;
-        rc = qldpc_recon_plan(g_recon, pb->workbits, qplan, &msg);
+        rc = qldpc_recon_plan(ldpc_engineFor(pb), pb->workbits, qplan, &msg);
     }
-    if (rc == QLDPC_EUNSUPPORTED) return LDPC_ERR_RATE;
+#ifdef LDPC_TEST_HOOKS
+    if (g_opt_noplan) rc = QLDPC_EUNSUPPORTED;
+#endif
+    if (rc == QLDPC_EUNSUPPORTED) {
+        /* The follower chose LDPC for a block this side has no code for (its estimate sits at the edge of the rate table).  The main
+         * loop drops a handler's return value (ecd2.c:524), so an error code alone would leave both daemons waiting: send a header that
+         * says "no plan" instead.  The follower refuses it like any header its own table does not give, answers with a failed verdict,
+         * and both sides go on with cascade (or drop the block where cascade cannot take it). */
+        memset(&msg, 0, sizeof(msg));
+        msg.rate_index = LDPC_NO_PLAN; msg.key_bits = (uint32_t)pb->workbits;
+        printf("ldpc: epoch %08x: no code in the rate table for QBER %.4f, telling the follower (error %d would be: %s)\n", pb->startEpoch, (double)qplan, LDPC_ERR_RATE,
+               "QBER too high for the LDPC rate table");
+        fflush(stdout);
+        if ((errorCode = ldpc_sendParityPackets(pb, &msg, NULL, 0, &fragCount))) return errorCode;
+        ld->msg = msg; ld->planQber = qplan; ld->round = 1;      /* nothing withheld: no second round */
+        pb->processingState = PSTATE_PERFORMED_PARITY;
+        pb->leakageBits += qldpc_recon_leaked_bits(&msg);          /* what the follower charges for a refused header: the (unused) CRC */
+        return 0;
+    }
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
     parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
     parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
     if (!parity) return 43;
-    rc = qldpc_recon_encode(g_recon, pb->mainBufPtr, pb->workbits, qplan, &msg, parity, (int)parityWords);
+    rc = qldpc_recon_encode(ldpc_engineFor(pb), pb->mainBufPtr, pb->workbits, qplan, &msg, parity, (int)parityWords);
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
-    {   /* fault injection for tests of the fallback path: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits (of the FIRST message) */
+#ifdef LDPC_TEST_HOOKS
+    {   /* fallback-path tests: -L x<n> / ECD2_LDPC_FAULT=n flips n disclosed parity bits (of the FIRST message) */
         const int n = g_opt_fault >= 0 ? g_opt_fault : ldpc_envInt("ECD2_LDPC_FAULT", 0), disclosed = (int)(msg.code_m - msg.n_punct);
         int i;
         for (i = 0; i < n && i < disclosed; i++) {
@@ -351,6 +400,7 @@ int ldpc_initiateAfterQber(ProcessBlock *pb)
             parity[pos / 32] ^= 1u << (31 - pos % 32);
         }
     }
+#endif
     errorCode = ldpc_sendParityPackets(pb, &msg, parity, parityWords, &fragCount);
     free2(parity);
     if (errorCode) return errorCode;
@@ -378,7 +428,7 @@ static int ldpc_sendWithheldParity(ProcessBlock *pb)
     parityWords = (unsigned int)qldpc_recon_parity_words(&msg);
     parity = (uint32_t *)malloc2(parityWords * WORD_SIZE + WORD_SIZE);
     if (!parity) return 43;
-    rc = qldpc_recon_encode_planned(g_recon, pb->mainBufPtr, pb->workbits, &msg, parity, (int)parityWords);
+    rc = qldpc_recon_encode_planned(ldpc_engineFor(pb), pb->mainBufPtr, pb->workbits, &msg, parity, (int)parityWords);
     if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); free2(parity); return LDPC_ERR_ENGINE; }
     errorCode = ldpc_sendParityPackets(pb, &msg, parity, parityWords, &fragCount);
     free2(parity);
@@ -397,14 +447,15 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
 
 /* one fragment of a block's parity: validate it against the block and against the fragments seen so far, copy its words.
  * returns 0 and *complete = 1 once every fragment is there; a packet for a block that is not waiting for parity (a duplicate after
- * completion, a packet for the wrong role) is ignored (*complete = 0). */
+ * completion, a packet for the wrong role) is ignored (*complete = 0).  LDPC_ERR_PKT_SIZE = a malformed packet for a block that IS
+ * waiting: the caller answers it with a failed verdict (the main loop drops handler return values, ecd2.c:524). */
 static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *complete)
 {
     const EcPktHdr_LdpcParity *in = (const EcPktHdr_LdpcParity *)receivebuf;
     LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
-    unsigned int totalWords, words;
+    unsigned int totalWords, words, per;
     *complete = 0;
-    if (pb->processorRole != PROC_ROLE_EC_FOLLOWER || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !ld) return LDPC_ERR_PKT_SIZE;
+    if (pb->processorRole != PROC_ROLE_EC_FOLLOWER || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !ld) return 0;   /* not ours to answer */
     if (ld->parityState != 0) return 0;                              /* already complete (queued or decoding): a repeated packet */
     if (ld->round == 1 && in->nPunct != 0) return 0;                 /* a late copy of the first message after the second round was asked for */
     if (in->base.totalLengthInBytes < sizeof(EcPktHdr_LdpcParity) || in->base.totalLengthInBytes > LDPC_MAX_PACKET_BYTES) return LDPC_ERR_PKT_SIZE;
@@ -414,17 +465,24 @@ static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *co
     words = (in->base.totalLengthInBytes - sizeof(EcPktHdr_LdpcParity)) / WORD_SIZE;
     if (in->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcParity) + words * WORD_SIZE) return LDPC_ERR_PKT_SIZE;
     if (in->fragWordOffset > totalWords || words > totalWords - in->fragWordOffset) return LDPC_ERR_PKT_SIZE;
+    /* placement is tied to the fragment index: every fragment but the last carries `per` words and starts at fragIndex * per, the
+     * last one ends the payload -- no gaps, no overlaps, whatever order they arrive in */
+    if (in->fragIndex + 1 < in->fragCount) per = words;
+    else per = in->fragCount > 1 ? in->fragWordOffset / (in->fragCount - 1) : totalWords;
+    if (in->fragWordOffset != in->fragIndex * per || (in->fragIndex + 1 == in->fragCount && in->fragWordOffset + words != totalWords) ||
+        (in->fragCount > 1 && per == 0)) return LDPC_ERR_PKT_SIZE;
     if (!ld->parityWords) {
         qldpc_recon_msg first;
         memset(&first, 0, sizeof(first));
         first.rate_index = in->rateIndex; first.key_bits = in->keyBits; first.code_k = in->codeK; first.code_m = in->codeM;
         first.crc32 = in->crc32; first.n_punct = in->nPunct;
         /* the dimensions must be what THIS side's rate table gives for the block before anything is allocated for the payload */
-        if (qldpc_recon_check_header(g_recon, &first, pb->workbits) != QLDPC_OK) {
+        if (qldpc_recon_check_header(ldpc_engineFor(pb), &first, pb->workbits) != QLDPC_OK) {
             /* answer it (the initiator waits for a verdict): failed, i.e. both sides fall back to cascade; what the packet says was disclosed
-             * is charged to the leakage account */
-            printf("ldpc: epoch %08x: parity header refused (%s)\n", pb->startEpoch, qldpc_last_error());
-            ld->parityState = 1;
+             * is charged to the leakage account.  The initiator's "no plan" header (LDPC_NO_PLAN) ends here too. */
+            if (in->rateIndex == LDPC_NO_PLAN) printf("ldpc: epoch %08x: the initiator has no code for this block\n", pb->startEpoch);
+            else printf("ldpc: epoch %08x: parity header refused (%s)\n", pb->startEpoch, qldpc_last_error());
+            ld->parityState = 1; ld->round = 1;
             return ldpc_finishBlock(pb, &first, 0, 0, 0);
         }
         ld->parityWords = (unsigned int *)malloc2(totalWords * WORD_SIZE + WORD_SIZE);
@@ -433,13 +491,17 @@ static int ldpc_acceptFragment(ProcessBlock *pb, const char *receivebuf, int *co
         memset(&ld->msg, 0, sizeof(ld->msg));
         ld->msg.rate_index = in->rateIndex; ld->msg.key_bits = in->keyBits; ld->msg.code_k = in->codeK; ld->msg.code_m = in->codeM;
         ld->msg.crc32 = in->crc32; ld->msg.n_punct = in->nPunct;
-        ld->fragCount = in->fragCount; ld->fragsSeen = 0;
+        ld->fragCount = in->fragCount; ld->fragsSeen = 0; ld->fragWords = per; ld->wordsSeen = 0;
     } else if (ld->msg.rate_index != in->rateIndex || ld->msg.code_k != in->codeK || ld->msg.code_m != in->codeM || ld->msg.crc32 != in->crc32 ||
-               ld->msg.n_punct != in->nPunct || ld->fragCount != in->fragCount) return LDPC_ERR_PKT_SIZE;      /* fragments must agree */
+               ld->msg.n_punct != in->nPunct || ld->fragCount != in->fragCount || ld->fragWords != per) return LDPC_ERR_PKT_SIZE;      /* fragments must agree */
     if (ld->fragsSeen & (1u << in->fragIndex)) return 0;             /* this fragment again */
     memcpy(ld->parityWords + in->fragWordOffset, receivebuf + sizeof(EcPktHdr_LdpcParity), words * WORD_SIZE);
     ld->fragsSeen |= 1u << in->fragIndex;
-    if (ld->fragsSeen == (ld->fragCount >= 32 ? 0xFFFFFFFFu : (1u << ld->fragCount) - 1u)) { ld->parityState = 1; *complete = 1; }
+    ld->wordsSeen += words;
+    if (ld->fragsSeen == (ld->fragCount >= 32 ? 0xFFFFFFFFu : (1u << ld->fragCount) - 1u)) {
+        if (ld->wordsSeen != totalWords) return LDPC_ERR_PKT_SIZE;   /* cannot happen given the placement rule; kept as the invariant it is */
+        ld->parityState = 1; *complete = 1;
+    }
     return 0;
 }
 
@@ -476,10 +538,15 @@ static int ldpc_finishBlock(ProcessBlock *pb, const qldpc_recon_msg *msg, int de
     }
     ld->rateIndex = msg->rate_index; ld->codeK = msg->code_k; ld->codeM = msg->code_m; ld->iterations = iterations;
     printf("ldpc: epoch %08x: decoded %d key bits in %d iterations, %d errors corrected, %d bits leaked (code sets built so far: %ld)\n", pb->startEpoch, pb->workbits,
-           iterations, corrected, leaked, qldpc_recon_entries_created(g_recon));
+           iterations, corrected, leaked, qldpc_recon_entries_created(ldpc_engineFor(pb)));
     fflush(stdout);
+    /* Leakage account.  privAmp_doPrivAmp (priv_amp.c:86-90,166) ends with finalKeyBits = workbits - (leakageBits + sneakloss) +
+     * correctedErrors: the last term is cascade's -- every error its binary search locates made one disclosed parity bit redundant.
+     * An LDPC message holds no such redundancy (every disclosed parity bit and the CRC count in full), so the credit is charged
+     * back here, on both sides alike (the initiator does the same in ldpc_receiveVerdict): the key ends workbits - leaked - sneakloss
+     * bits long.  correctedErrors itself stays what it is: the sneakloss term is made of it. */
     pb->correctedErrors = corrected;
-    pb->leakageBits += leaked;
+    pb->leakageBits += leaked + corrected;
     pb->processingState = PSTATE_PERFORMED_PARITY;
     /* same hand-over as cascade_biconf.c:892,939: send message 8 and do the PA locally */
     return privAmp_sendPrivAmpMsgAndPrivAmp(pb);
@@ -507,42 +574,55 @@ static int ldpc_batchSize(void)
 
 int ldpc_pending(void) { return g_queued; }
 
-/* decode everything queued in ONE qldpc_recon_decode_blocks call.  Every block is looked up by epoch again (it may have been removed
- * since it queued), validated and answered on its own: a header the engine refuses gets a failed verdict, it does not fail the batch. */
+/* decode everything queued: ONE qldpc_recon_decode_blocks call per device in use.  Every block is looked up by epoch again (it may
+ * have been removed since it queued), validated and answered on its own: a header the engine refuses gets a failed verdict, it does
+ * not fail the batch; an engine error fails every block of the call the same way (verdict 0 -> cascade or drop) instead of leaving
+ * them queued for ever -- the main loop would not see a return code (ecd2.c:524). */
 static int ldpc_flush(void)
 {
     uint32_t *keys[LDPC_BATCH_MAX];
     const uint32_t *pars[LDPC_BATCH_MAX];
-    unsigned int epochs[LDPC_BATCH_MAX];
+    unsigned int epochs[LDPC_BATCH_MAX], all[LDPC_BATCH_MAX];
     qldpc_recon_msg msgs[LDPC_BATCH_MAX];
     int bits[LDPC_BATCH_MAX], status[LDPC_BATCH_MAX], corrected[LDPC_BATCH_MAX], iterations[LDPC_BATCH_MAX];
     float qber[LDPC_BATCH_MAX];
-    int n = 0, i, rc, errorCode = 0;
+    int n, i, d, rc, errorCode = 0, total = g_queued, decodedBlocks = 0;
 
-    for (i = 0; i < g_queued; i++) {
-        ProcessBlock *pb = pBlkMgmt_getProcessBlk(g_queue[i]);
-        LdpcData *ld;
-        if (!pb || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !(ld = (LdpcData *)pb->algorithmDataPtr) || ld->parityState != 1) continue;
-        epochs[n] = g_queue[i]; keys[n] = pb->mainBufPtr; bits[n] = pb->workbits; qber[n] = pb->localError;
-        msgs[n] = ld->msg; pars[n] = ld->parityWords;
-        n++;
-    }
+    memcpy(all, g_queue, sizeof(unsigned int) * (size_t)g_queued);
     g_queued = 0;
-    if (n == 0) return 0;
-    rc = qldpc_recon_decode_blocks(g_recon, n, keys, bits, qber, msgs, pars, status, corrected, iterations);
-    if (rc != QLDPC_OK) { fprintf(stderr, "ldpc: %s\n", qldpc_last_error()); return LDPC_ERR_ENGINE; }
-    if (ldpc_batchSize() > 1) printf("ldpc: decoded a batch of %d blocks in one call\n", n);
-    for (i = 0; i < n; i++) {
-        ProcessBlock *pb = pBlkMgmt_getProcessBlk(epochs[i]);      /* finishing a block removes it (privacy amplification): never keep the pointer */
-        int e;
-        if (!pb) continue;
-        if (status[i] == QLDPC_ESIZE) {
-            printf("ldpc: epoch %08x: parity header refused (%s)\n", epochs[i], qldpc_last_error());
-            if (pb->algorithmDataPtr) ((LdpcData *)pb->algorithmDataPtr)->round = 1;      /* nothing to ask a second round of: failed verdict */
+    for (d = 0; d < g_devices; d++) {
+        n = 0;
+        for (i = 0; i < total; i++) {
+            ProcessBlock *pb = pBlkMgmt_getProcessBlk(all[i]);
+            LdpcData *ld;
+            if (!pb || ldpc_deviceOf(all[i], g_devices) != d) continue;
+            if (pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !(ld = (LdpcData *)pb->algorithmDataPtr) || ld->parityState != 1) continue;
+            epochs[n] = all[i]; keys[n] = pb->mainBufPtr; bits[n] = pb->workbits; qber[n] = pb->localError;
+            msgs[n] = ld->msg; pars[n] = ld->parityWords;
+            n++;
         }
-        e = ldpc_finishBlock(pb, &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
-        if (e && !errorCode) errorCode = e;
+        if (n == 0) continue;
+        rc = qldpc_recon_decode_blocks(g_recons[d], n, keys, bits, qber, msgs, pars, status, corrected, iterations);
+        if (rc != QLDPC_OK) {
+            fprintf(stderr, "ldpc: device %d: %s\n", d, qldpc_last_error());
+            printf("ldpc: engine error on a batch of %d blocks (%s): failed verdicts\n", n, qldpc_last_error());
+            for (i = 0; i < n; i++) { status[i] = QLDPC_EDECODE; corrected[i] = 0; iterations[i] = 0; }
+            if (!errorCode) errorCode = LDPC_ERR_ENGINE;
+        }
+        decodedBlocks += n;
+        for (i = 0; i < n; i++) {
+            ProcessBlock *pb = pBlkMgmt_getProcessBlk(epochs[i]);      /* finishing a block removes it (privacy amplification): never keep the pointer */
+            int e;
+            if (!pb) continue;
+            if (status[i] == QLDPC_ESIZE || rc != QLDPC_OK) {
+                if (rc == QLDPC_OK) printf("ldpc: epoch %08x: parity header refused (%s)\n", epochs[i], qldpc_last_error());
+                if (pb->algorithmDataPtr) ((LdpcData *)pb->algorithmDataPtr)->round = 1;      /* nothing to ask a second round of: failed verdict */
+            }
+            e = ldpc_finishBlock(pb, &msgs[i], status[i] == QLDPC_OK, corrected[i], iterations[i]);
+            if (e && !errorCode) errorCode = e;
+        }
     }
+    if (ldpc_batchSize() > 1 && decodedBlocks) printf("ldpc: decoded a batch of %d blocks in one call\n", decodedBlocks);
     return errorCode;
 }
 
@@ -562,7 +642,24 @@ int ldpc_tick(int receiveQueueEmpty)
 int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
 {
     int complete = 0, errorCode, i;
-    if ((errorCode = ldpc_acceptFragment(pb, receivebuf, &complete))) return errorCode;
+    if ((errorCode = ldpc_acceptFragment(pb, receivebuf, &complete))) {
+        LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+        if (errorCode == LDPC_ERR_PKT_SIZE && ld && ld->parityState == 0) {
+            /* a malformed packet for a block that waits for its parity: say so and answer with a failed verdict (the initiator must not be
+             * left waiting, and the main loop drops this return value).  What the block has been told was disclosed is charged: the plan
+             * of the fragments accepted so far, else the header's own figures when they are sane. */
+            const EcPktHdr_LdpcParity *in = (const EcPktHdr_LdpcParity *)receivebuf;
+            qldpc_recon_msg m;
+            memset(&m, 0, sizeof(m));
+            if (ld->parityWords) m = ld->msg;
+            else if (in->base.totalLengthInBytes >= sizeof(EcPktHdr_LdpcParity) && in->nPunct <= in->codeM && in->codeM <= (1u << 26)) { m.code_m = in->codeM; m.n_punct = in->nPunct; }
+            printf("ldpc: epoch %08x: malformed parity packet (error %d), failed verdict\n", pb->startEpoch, errorCode);
+            fflush(stdout);
+            ld->parityState = 1; ld->round = 1;
+            return ldpc_finishBlock(pb, &m, 0, 0, 0);
+        }
+        return errorCode;
+    }
     if (!complete) return 0;                                         /* more fragments to come, or a packet that changes nothing */
     for (i = 0; i < g_queued; i++) if (g_queue[i] == pb->startEpoch) return 0;
     if (g_queued == 0) clock_gettime(CLOCK_MONOTONIC, &g_first);
@@ -576,10 +673,16 @@ int ldpc_receiveParity(ProcessBlock *pb, char *receivebuf)
 int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
 {
     EcPktHdr_LdpcVerdict *in_head = (EcPktHdr_LdpcVerdict *)receivebuf;
-    if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) return LDPC_ERR_PKT_SIZE;
+    LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
+    /* both roles share one handler table: a verdict is only meaningful to an EC initiator that sent parity and holds LDPC data */
+    if (pb->processorRole != PROC_ROLE_EC_INITIATOR || pb->algorithmDataMngr != (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_LDPC || !ld ||
+        pb->processingState != PSTATE_PERFORMED_PARITY) {
+        printf("ldpc: epoch %08x: verdict packet ignored (not an LDPC initiator waiting for one)\n", pb->startEpoch);
+        return 0;
+    }
+    if (in_head->base.totalLengthInBytes != sizeof(EcPktHdr_LdpcVerdict)) { printf("ldpc: epoch %08x: verdict packet of %u bytes ignored\n", pb->startEpoch, in_head->base.totalLengthInBytes); return LDPC_ERR_PKT_SIZE; }
     if (in_head->decoded == 2) {      /* the follower asks for the withheld parity bits (once) */
-        LdpcData *ld = (LdpcData *)pb->algorithmDataPtr;
-        if (!ld || ld->round != 0 || ld->msg.n_punct == 0 || pb->processorRole != PROC_ROLE_EC_INITIATOR) return LDPC_ERR_PKT_SIZE;
+        if (ld->round != 0 || ld->msg.n_punct == 0) { printf("ldpc: epoch %08x: second-round request ignored\n", pb->startEpoch); return LDPC_ERR_PKT_SIZE; }
         return ldpc_sendWithheldParity(pb);
     }
     if (!in_head->decoded) {
@@ -588,6 +691,7 @@ int ldpc_receiveVerdict(ProcessBlock *pb, char *receivebuf)
         return (arguments.runtimeErrorMode == END_ON_ERR) ? LDPC_ERR_DECODE_FAILED : 0;
     }
     pb->correctedErrors = (int)in_head->correctedBits;
-    ((LdpcData *)pb->algorithmDataPtr)->iterations = (int)in_head->iterations;
+    pb->leakageBits += (int)in_head->correctedBits;      /* cancels privAmp_doPrivAmp's cascade-specific credit, as the follower does (ldpc_finishBlock) */
+    ld->iterations = (int)in_head->iterations;
     return 0;   /* message 8 (privAmp_receivePrivAmpMsg) follows and finishes the block */
 }

@@ -16,6 +16,13 @@
 #ifndef ECD2_LDPC_RECONCILE
 #define ECD2_LDPC_RECONCILE
 
+/* `-L D<n>`: which of n devices takes the block that starts at `epoch` (in the daemon multi-GPU means replicas only --
+ * blocks go round-robin to devices, nothing is exchanged between them).  Each side chooses for itself; the two need not agree. */
+#define LDPC_MAX_DEVICES 8
+static inline int ldpc_deviceOf(unsigned int epoch, int n_devices) { return n_devices > 1 ? (int)(epoch % (unsigned int)n_devices) : 0; }
+
+#ifndef LDPC_DEVICE_CHOICE_ONLY      /* (a unit test compiles the function above without the daemon's headers) */
+
 #include "definitions/algorithms/algorithms.h"   /* ProcessBlock, packet/data managers, ALGORITHM_DECISION */
 #include "definitions/packets.h"
 #include "qldpc.h"
@@ -47,6 +54,8 @@ typedef struct ERRC_LDPC_9 {
 } EcPktHdr_LdpcParity;
 #define LDPC_MAX_PACKET_BYTES 10000
 #define LDPC_MAX_FRAGMENTS 32
+#define LDPC_NO_PLAN 0xFFFFFFFFu  /**< rateIndex of a header without payload: "this side's rate table has no code for the block" -- the follower
+                                       answers with a failed verdict and both sides continue with cascade */
 
 /** @brief subtype 10: verdict */
 typedef struct ERRC_LDPC_10 {
@@ -66,6 +75,8 @@ typedef struct ALGORITHM_LDPC_DATA {
     unsigned int *parityWords;    /**< malloc2'ed on the first fragment, ceil((codeM - nPunct)/32) words */
     unsigned int fragsSeen;       /**< bit i = fragment i has arrived                                 */
     unsigned int fragCount;
+    unsigned int fragWords;       /**< words every fragment but the last carries (fragment i starts at i * fragWords)  */
+    unsigned int wordsSeen;       /**< payload words placed so far                                                      */
     int parityState;              /**< 0 awaiting fragments, 1 complete and queued / being decoded   */
     int round;                    /**< 0: first parity message; 1: the withheld bits were asked for (follower) / sent (initiator) */
     float planQber;               /**< EC initiator: the error rate the block was planned for         */
@@ -80,11 +91,12 @@ extern const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC;
 int ldpc_init(int device);
 /** the daemon's `-L` option (free in ecd2.c:26's getopt string): `-L 1` = choose LDPC after QBER estimation (qber_estim.c:301),
  *  `-L b<n>` batch size of the batched ingest, `-L w<ms>` its wait, `-L g` privacy amplification on the GPU, `-L f0` no cascade
- *  fallback, `-L r0` no second round (the withheld parity bits after a failed decode), `-L p<bytes>` largest parity packet; several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
+ *  fallback, `-L r0` no second round (the withheld parity bits after a failed decode), `-L p<bytes>` largest parity packet, `-L D<n>` blocks round-robin over n devices (ldpc_deviceOf); several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
 int ldpc_parseOption(const char *optarg);
 int ldpc_selected(void);          /**< 1 after `-L 1` (or ECD2_LDPC=1 in the environment) */
 int ldpc_selectedFor(const ProcessBlock *pb);      /**< the per-block choice: selected AND the rate table covers the block's estimated QBER */
 int ldpc_gpuPrivAmp(void);        /**< 1 after `-L g` (or ECD2_GPU_PA=1)                   */
+int ldpc_deviceForBlock(const ProcessBlock *pb);   /**< the device (0 .. n-1 of `-L D<n>`) this block's decode / hash runs on */
 void ldpc_shutdown(void);
 
 /** batched ingest (ECD2_LDPC_BATCH=n): call ldpc_tick(receivedPacketLinkedList == NULL) once per main-loop iteration (ecd2.c, after
@@ -102,4 +114,5 @@ int ldpc_initiateAfterQber(ProcessBlock *processBlock);
 int ldpc_receiveParity(ProcessBlock *processBlock, char *receivebuf);
 int ldpc_receiveVerdict(ProcessBlock *processBlock, char *receivebuf);
 
+#endif /* LDPC_DEVICE_CHOICE_ONLY */
 #endif

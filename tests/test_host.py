@@ -321,3 +321,20 @@ def test_gf2_elimination_orders_give_systematic_generators(q, gold, order, name)
     libc = C.CDLL(None)
     for p in (piv, fr, A):
         libc.free(C.cast(p, C.c_void_p))
+
+
+def test_chunked_crc_equals_the_bytewise_crc(q):
+    """The device verification of the sessions (rk_verify / rk_crc in qldpc_recon.hip) computes CRC-32 as a fold of per-lane partial
+    registers with x^len multipliers mod the CRC polynomial; qldpc_crc32_words_chunked is that arithmetic on the host.  It must
+    equal the byte-wise table CRC (and zlib) for every length and every lane count, tail bits masked."""
+    import zlib
+    rng = np.random.default_rng(0)
+    for nb in (1, 31, 32, 33, 64, 100, 1000, 8191, 8192, 52429, 65535, 65536, 120002, 262144):
+        w = rng.integers(0, 2 ** 32, (nb + 31) // 32, dtype=np.uint64).astype(np.uint32)
+        ref = q.crc32_words(w, nb)
+        masked = w.copy()
+        if nb & 31:
+            masked[-1] &= np.uint32((0xFFFFFFFF << (32 - (nb & 31))) & 0xFFFFFFFF)
+        assert ref == zlib.crc32(masked.astype(">u4").tobytes())
+        for lanes in (1, 2, 8, 64, 256):
+            assert q.crc32_words(w, nb, lanes) == ref, (nb, lanes)
