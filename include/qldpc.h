@@ -280,6 +280,9 @@ int qldpc_last_run_stats(qldpc_decoder *dec, long long out[4]);
  * VAR/main.cpp (qc):145: info bits first, parity = H2^-1 H1 u; QLDPC_EUNSUPPORTED when H2 is singular). */
 int qldpc_encoder_create(const qldpc_code *code, const char *method, int device, qldpc_encoder **out);
 void qldpc_encoder_free(qldpc_encoder *enc);
+/* Size the encoder's device workspace for calls of up to max_frames frames now (it otherwise grows on first need): a caller that must not
+ * allocate later -- the daemon after ldpc_init -- says so here.  One encoder is not re-entrant (neither is an AFF3CT module). */
+int qldpc_encoder_reserve(qldpc_encoder *enc, int max_frames);
 int qldpc_encoder_k(const qldpc_encoder *enc);
 int qldpc_encoder_info_bits_pos(const qldpc_encoder *enc, int *pos /* K */);
 /* host mirror of encoder->encode: U_K[n_frames][K] ints -> X_N[n_frames][N] ints. */

@@ -124,6 +124,7 @@ _sig("qldpc_last_run_iterations", C.c_int, [_vp])
 _sig("qldpc_last_run_stats", C.c_int, [_vp, C.POINTER(C.c_longlong)])
 _sig("qldpc_encoder_create", C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(_vp)])
 _sig("qldpc_encoder_free", None, [_vp])
+_sig("qldpc_encoder_reserve", C.c_int, [_vp, C.c_int])
 _sig("qldpc_encoder_k", C.c_int, [_vp])
 _sig("qldpc_encoder_info_bits_pos", C.c_int, [_vp, _ip])
 _sig("qldpc_encode", C.c_int, [_vp, _ip, _ip, C.c_int])

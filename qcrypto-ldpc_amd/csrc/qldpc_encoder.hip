@@ -42,7 +42,21 @@ struct qldpc_encoder {
     int *d_cn_ptr, *d_cn_var;
     /* IDENTITY */
     uint32_t *d_A; int wpr;  /* [R][wpr] MSB-first rows over the info index */
+    uint8_t *d_par; size_t par_frames;   /* workspace: parity bytes [frames][R] of the call in flight (one encoder is not re-entrant) */
 };
+
+/* the workspace holds n_frames frames: grown (never shrunk) with plain hipMalloc -- after a device-wide synchronisation, so nothing in
+ * flight still uses the old block -- and kept; qldpc_encoder_reserve sizes it up front so that no call allocates later */
+static int ensure_workspace(qldpc_encoder *e, int n_frames)
+{
+    if ((size_t)n_frames <= e->par_frames) return QLDPC_OK;
+    HIPCHK(hipDeviceSynchronize());
+    if (e->d_par) (void)hipFree(e->d_par);
+    e->d_par = nullptr; e->par_frames = 0;
+    if (hipMalloc((void **)&e->d_par, (size_t)n_frames * (size_t)e->R) != hipSuccess) { qldpc_set_error("encoder workspace: hipMalloc(%zu bytes) failed", (size_t)n_frames * (size_t)e->R); return QLDPC_ENOMEM; }
+    e->par_frames = (size_t)n_frames;
+    return QLDPC_OK;
+}
 
 __device__ __forceinline__ uint32_t getbit(const uint32_t *w, int i) { return (w[i >> 5] >> (31 - (i & 31))) & 1u; }
 
@@ -107,7 +121,7 @@ extern "C" void qldpc_encoder_free(qldpc_encoder *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    (void)hipFree(e->d_map); (void)hipFree(e->d_cn_ptr); (void)hipFree(e->d_cn_var); (void)hipFree(e->d_A);
+    (void)hipFree(e->d_map); (void)hipFree(e->d_cn_ptr); (void)hipFree(e->d_cn_var); (void)hipFree(e->d_A); (void)hipFree(e->d_par);
     delete e;
 }
 
@@ -157,11 +171,18 @@ extern "C" int qldpc_encoder_create(const qldpc_code *code, const char *method, 
     if (!code || !method) return QLDPC_EINVAL;
     qldpc_encoder *e = new (std::nothrow) qldpc_encoder();
     if (!e) return QLDPC_ENOMEM;
-    e->d_map = nullptr; e->d_cn_ptr = nullptr; e->d_cn_var = nullptr; e->d_A = nullptr; e->wpr = 0;
+    e->d_map = nullptr; e->d_cn_ptr = nullptr; e->d_cn_var = nullptr; e->d_A = nullptr; e->wpr = 0; e->d_par = nullptr; e->par_frames = 0;
     int rc = enc_create(code, method, device, e);
     if (rc != QLDPC_OK) { qldpc_encoder_free(e); return rc; }
     *out = e;
     return QLDPC_OK;
+}
+
+extern "C" int qldpc_encoder_reserve(qldpc_encoder *e, int max_frames)
+{
+    if (!e || max_frames <= 0) return QLDPC_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    return ensure_workspace(e, max_frames);
 }
 
 extern "C" int qldpc_encoder_k(const qldpc_encoder *e) { return e ? e->K : QLDPC_EINVAL; }
@@ -179,8 +200,9 @@ extern "C" int qldpc_encode_packed_dev(qldpc_encoder *e, const uint32_t *d_info,
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const int Wk = (e->K + 31) / 32, Wn = (e->N + 31) / 32;
-    uint8_t *par = nullptr;
-    HIPCHK(hipMallocAsync((void **)&par, (size_t)n_frames * (size_t)e->R, st));
+    int rc = ensure_workspace(e, n_frames);
+    if (rc) return rc;
+    uint8_t *par = e->d_par;
     if (e->ira) {
         hipLaunchKernelGGL(qe_ira_syndrome, dim3((unsigned)((e->M + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, d_info, e->d_cn_ptr, e->d_cn_var, par, e->M, e->K, Wk);
         hipLaunchKernelGGL(qe_prefix_xor, dim3((unsigned)n_frames), dim3(64), 0, st, par, e->M);
@@ -189,7 +211,6 @@ extern "C" int qldpc_encode_packed_dev(qldpc_encoder *e, const uint32_t *d_info,
     }
     hipLaunchKernelGGL(qe_assemble, dim3((unsigned)((Wn + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, d_info, par, e->d_map, d_cw, e->N, Wn, Wk, e->R);
     hipError_t le = hipGetLastError();
-    HIPCHK(hipFreeAsync(par, st));
     if (le != hipSuccess) { qldpc_set_error("encode: kernel launch -> %s", hipGetErrorString(le)); return QLDPC_EHIP; }
     return QLDPC_OK;
 }

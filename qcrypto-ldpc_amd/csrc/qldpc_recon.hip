@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -406,12 +408,21 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     if (hipSetDevice(cfg->device) != hipSuccess) { delete r; return QLDPC_EHIP; }
     /* the session's own streams: nothing of it runs on the null stream, so a second session or other work on the device does not
      * serialise behind it */
-    for (auto &l : r->lane)
-        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&l.copy, hipStreamNonBlocking) != hipSuccess) {
-            qldpc_set_error("recon_create: hipStreamCreate failed");
-            qldpc_recon_free(r);
-            return QLDPC_EHIP;
-        }
+    /* the runtime binds a stream to one of its few hardware queues when the stream is created, round robin: the compute streams are
+     * created back to back so that the lanes land on different queues (interleaved with the copy streams, four lanes shared two queues
+     * and at most two kernels ever ran side by side: rocprofv3 kernel trace, profiles/r03_config3_*) */
+    bool ok = true;
+    const bool interleave = getenv("QLDPC_RECON_STREAMS_INTERLEAVED") != nullptr;      /* A/B: the old order */
+    if (interleave) { for (auto &l : r->lane) ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&l.copy, hipStreamNonBlocking) == hipSuccess; }
+    else {
+        for (auto &l : r->lane) ok = ok && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess;
+        for (auto &l : r->lane) ok = ok && hipStreamCreateWithFlags(&l.copy, hipStreamNonBlocking) == hipSuccess;
+    }
+    if (!ok) {
+        qldpc_set_error("recon_create: hipStreamCreate failed");
+        qldpc_recon_free(r);
+        return QLDPC_EHIP;
+    }
     if (cfg->preload && mothers) {
         /* every (mother size, table rate) pair now: code, encoder, decoder and staging buffers, so that no block of up to mother_max
          * bits builds a code or allocates device memory later (the daemon calls this from ldpc_init) */
@@ -523,6 +534,7 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     const int N = K + M, Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32, B = r->cfg.max_blocks;
     int rc = r->cfg.peg_depth > 0 ? qldpc_code_ira_peg(N, K, 0.125f, 11, 3, r->cfg.peg_depth, r->cfg.seed, &e.code) : qldpc_code_ira(N, K, 0.125f, 11, 3, r->cfg.seed, &e.code);
     if (!rc) rc = qldpc_encoder_create(e.code, "IRA", r->cfg.device, &e.enc);
+    if (!rc) rc = qldpc_encoder_reserve(e.enc, B);      /* nothing is allocated per block later */
     if (!rc) {
         qldpc_decoder_cfg dc;
         qldpc_decoder_cfg_default(&dc);
@@ -748,6 +760,8 @@ static int job_finish(lane_run *L, recon_job &j)
 static void lane_main(lane_run *L)
 {
     int rc = QLDPC_OK;
+    const bool dbg = getenv("QLDPC_DEBUG") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
     if (hipSetDevice(L->r->cfg.device) != hipSuccess) { L->rc = QLDPC_EHIP; L->err = "hipSetDevice failed"; return; }
     const size_t nj = L->jobs.size();
     /* one job: everything in order on the compute stream (no cross-stream hand-offs on the daemon's one-block path) */
@@ -760,6 +774,12 @@ static void lane_main(lane_run *L)
         if (!rc && i > 0) { rc = job_finish(L, L->jobs[i - 1]); if (!rc) finished = i; }
     }
     for (size_t i = finished; i < launched && !rc; i++) rc = job_finish(L, L->jobs[i]);
+    if (dbg) {
+        size_t blocks = 0;
+        for (auto &j : L->jobs) blocks += j.idx.size();
+        fprintf(stderr, "libqldpc: recon lane %d: %zu job(s), %zu blocks, first code K %d M %d, %.3f ms\n", (int)(L->lane - L->r->lane), nj, blocks, L->jobs[0].e->K, L->jobs[0].e->M,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    }
     if (rc) {
         L->err = qldpc_last_error();
         (void)hipStreamSynchronize(L->lane->stream);
@@ -787,6 +807,11 @@ static int run_call(qldpc_recon *r, const recon_call &call, const std::vector<ch
             if (!taken[(size_t)j] && mj.code_k == mi.code_k && mj.code_m == mi.code_m) { g.idx.push_back(j); taken[(size_t)j] = 1; }
         }
         if ((rc = get_entry(r, (int)mi.code_k, (int)mi.code_m, &g.e))) { cache_trim(r); return rc; }
+        /* Bob: a 64-frame group of the decoder runs until its slowest frame has converged, so frames that need about the same number of
+         * iterations belong together.  Within one mother code the plan leaves low-QBER blocks closest to capacity (the gap binds there, the
+         * configured efficiency further up), i.e. the iteration count falls with the QBER: order the blocks of a group by it. */
+        if (call.bob && !getenv("QLDPC_RECON_NOSORT"))
+            std::stable_sort(g.idx.begin(), g.idx.end(), [&](int a, int b) { return call.qber[a] < call.qber[b]; });
         g.cost = (double)g.idx.size() * (double)(mi.code_k + mi.code_m);
         groups.push_back(std::move(g));
     }

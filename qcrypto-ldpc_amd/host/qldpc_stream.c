@@ -12,6 +12,7 @@
  * prints one JSON object on stdout.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,12 +45,20 @@ static int die(const char *what, int rc)
     return 1;
 }
 
+struct part { qldpc_recon *r; int n; uint32_t **keys; int *kb; float *qber; qldpc_recon_msg *msgs; const uint32_t **pars; int *status, *corrected, *iters; int rc; };
+static void *part_main(void *arg)
+{
+    struct part *p = arg;
+    p->rc = qldpc_recon_decode_blocks(p->r, p->n, p->keys, p->kb, p->qber, p->msgs, p->pars, p->status, p->corrected, p->iters);
+    return NULL;
+}
+
 int main(int argc, char **argv)
 {
-    int epochs = 512, key_bits = 52429, batch = 256, reps = 3, layered = 0, profile = 0, peg = 0, opt;
+    int epochs = 512, key_bits = 52429, batch = 256, reps = 3, layered = 0, profile = 0, peg = 0, opt, a_lanes = 0, b_lanes = 0, verbose = 0, split = 1;
     uint64_t seed = 42;
     double qmin = 0.005, qmax = 0.06, gap = 0.0;
-    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lpP:g:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lpP:g:A:B:vT:")) != -1) {
         switch (opt) {
         case 'e': epochs = atoi(optarg); break;
         case 'k': key_bits = atoi(optarg); break;
@@ -61,6 +70,10 @@ int main(int argc, char **argv)
         case 'p': profile = 1; break;
         case 'P': peg = atoi(optarg); break;
         case 'g': gap = atof(optarg); break;
+        case 'A': a_lanes = atoi(optarg); break;      /* lanes of Alice's / Bob's calls (QLDPC_RECON_LANES, set per call): diagnostics */
+        case 'B': b_lanes = atoi(optarg); break;
+        case 'v': verbose = 1; break;
+        case 'T': split = atoi(optarg); break;      /* experiment: T sessions on T host threads, each decoding every T-th epoch */
         default: fprintf(stderr, "usage: see the head of qldpc_stream.c\n"); return 2;
         }
     }
@@ -107,11 +120,65 @@ int main(int argc, char **argv)
     }
 
     /* Alice: first call builds the codes of the table, the second is timed */
+    char num[16];
+    if (a_lanes) { snprintf(num, sizeof(num), "%d", a_lanes); setenv("QLDPC_RECON_LANES", num, 1); }
     if ((rc = qldpc_recon_encode_blocks(ra, epochs, akeys, kb, qber, msgs, pars, cap))) return die("recon_encode_blocks", rc);
+    uint32_t *par_first = NULL;
+    qldpc_recon_msg *msg_first = NULL;
+    if (verbose) {
+        par_first = malloc((size_t)epochs * max_par * 4); msg_first = malloc((size_t)epochs * sizeof(*msgs));
+        memcpy(par_first, parbuf, (size_t)epochs * max_par * 4); memcpy(msg_first, msgs, (size_t)epochs * sizeof(*msgs));
+    }
     double t0 = now_s();
     if ((rc = qldpc_recon_encode_blocks(ra, epochs, akeys, kb, qber, msgs, pars, cap))) return die("recon_encode_blocks", rc);
     const double t_enc = now_s() - t0;
+    if (verbose) {
+        int diff = 0;
+        for (int e = 0; e < epochs; e++)
+            if (memcmp(&msg_first[e], &msgs[e], sizeof(*msgs)) || memcmp(par_first + (size_t)e * max_par, parbuf + (size_t)e * max_par, 4 * (size_t)qldpc_recon_parity_words(&msgs[e]))) {
+                if (diff < 8) fprintf(stderr, "alice: block %d (rate index %u) differs between her two calls (crc %08x vs %08x)\n", e, msgs[e].rate_index, msg_first[e].crc32, msgs[e].crc32);
+                diff++;
+            }
+        fprintf(stderr, "alice: %d of %d blocks differ between two identical encode calls\n", diff, epochs);
+        for (int e = 0; e < epochs; e++)
+            if (msgs[e].crc32 != qldpc_crc32_words(akeys[e], key_bits)) { fprintf(stderr, "alice: block %d: device CRC %08x, host CRC %08x\n", e, msgs[e].crc32, qldpc_crc32_words(akeys[e], key_bits)); break; }
+    }
+    if (b_lanes) { snprintf(num, sizeof(num), "%d", b_lanes); setenv("QLDPC_RECON_LANES", num, 1); }
 
+    if (split > 1) {
+        /* experiment: the stream dealt to `split` sessions, each on its own host thread (every split-th epoch), timed together */
+        struct part P[8];
+        pthread_t th[8];
+        if (split > 8) split = 8;
+        for (int t = 0; t < split; t++) {
+            struct part *p = &P[t];
+            memset(p, 0, sizeof(*p));
+            if ((rc = qldpc_recon_create(&cfg, &p->r))) return die("recon_create", rc);
+            p->keys = calloc((size_t)epochs, sizeof(*p->keys)); p->pars = calloc((size_t)epochs, sizeof(*p->pars)); p->kb = calloc((size_t)epochs, sizeof(int));
+            p->qber = calloc((size_t)epochs, sizeof(float)); p->msgs = calloc((size_t)epochs, sizeof(*msgs));
+            p->status = calloc((size_t)epochs, sizeof(int)); p->corrected = calloc((size_t)epochs, sizeof(int)); p->iters = calloc((size_t)epochs, sizeof(int));
+            int seen[8] = {0};
+            for (int e = 0; e < epochs; e++) {
+                const int ri = msgs[e].rate_index & 7;
+                if (seen[ri]++ % split != t) continue;      /* every split-th epoch OF EACH RATE: the rate groups are halved */
+                p->keys[p->n] = bkeys[e]; p->pars[p->n] = pars[e]; p->kb[p->n] = kb[e]; p->qber[p->n] = qber[e]; p->msgs[p->n] = msgs[e]; p->n++;
+            }
+        }
+        double bestT = 1e30;
+        int goodT = 0;
+        for (int rep = -1; rep < reps; rep++) {
+            memcpy(work, bob, (size_t)epochs * W * 4);
+            t0 = now_s();
+            for (int t = 0; t < split; t++) pthread_create(&th[t], NULL, part_main, &P[t]);
+            for (int t = 0; t < split; t++) pthread_join(th[t], NULL);
+            const double dt = now_s() - t0;
+            if (rep >= 0 && dt < bestT) bestT = dt;
+            goodT = 0;
+            for (int t = 0; t < split; t++) { if (P[t].rc) return die("decode (split)", P[t].rc); for (int i = 0; i < P[t].n; i++) goodT += P[t].status[i] == QLDPC_OK; }
+        }
+        printf("{\"experiment\": \"%d sessions on %d threads\", \"reconciled\": %d, \"ms_best\": %.3f, \"Mbit_s_best\": %.1f}\n", split, split, goodT, bestT * 1e3, (double)goodT * key_bits / bestT / 1e6);
+        return 0;
+    }
     /* Bob: one untimed pass builds his decoders, then `reps` timed passes over fresh copies of his keys */
     double best = 1e30, sum = 0.0;
     int good = 0;
@@ -123,6 +190,16 @@ int main(int argc, char **argv)
         rc = qldpc_recon_decode_blocks(rb, epochs, bkeys, kb, qber, msgs, (const uint32_t *const *)pars, status, corrected, iters);
         const double dt = now_s() - t0;
         if (rc) return die("recon_decode_blocks", rc);
+        if (verbose) {
+            int bad = 0, pos[8] = {0};
+            fprintf(stderr, "bob rep %d:", rep);
+            for (int e = 0; e < epochs; e++) {
+                const int ri = msgs[e].rate_index & 7;
+                if (status[e] != QLDPC_OK) { if (bad < 12) fprintf(stderr, " [blk %d rate %d pos-in-group %d it %d]", e, ri, pos[ri], iters[e]); bad++; }
+                pos[ri]++;
+            }
+            fprintf(stderr, " -> %d failed\n", bad);
+        }
         if (rep < 0) continue;
         sum += dt;
         if (dt < best) best = dt;
@@ -132,15 +209,20 @@ int main(int argc, char **argv)
             if (status[e] == QLDPC_OK && !memcmp(work + (size_t)e * W, alice + (size_t)e * W, (size_t)W * 4)) { good++; leaked += qldpc_recon_leaked_bits(&msgs[e]); }
         }
     }
-    int per_rate[8] = {0};
-    for (int e = 0; e < epochs; e++) per_rate[msgs[e].rate_index & 7]++;
+    int per_rate[8] = {0}, fail_rate[8] = {0}, maxed[8] = {0};
+    for (int e = 0; e < epochs; e++) {
+        per_rate[msgs[e].rate_index & 7]++;
+        if (!(status[e] == QLDPC_OK && !memcmp(work + (size_t)e * W, alice + (size_t)e * W, (size_t)W * 4))) fail_rate[msgs[e].rate_index & 7]++;
+        if (iters[e] >= cfg.n_ite) maxed[msgs[e].rate_index & 7]++;
+    }
     const double mean = sum / reps;
     printf("{\"workload\": \"%d epochs x %d bits, QBER ~ U[%.3f, %.3f] seed %llu, batches of <= %d blocks, %s, one decode_blocks call\", "
            "\"reconciled\": %d, \"epochs\": %d, \"ms_mean\": %.3f, \"ms_best\": %.3f, \"Mbit_s_mean\": %.1f, \"Mbit_s_best\": %.1f, "
-           "\"leaked_fraction\": %.4f, \"avg_iterations\": %.2f, \"alice_encode_ms\": %.3f, \"epochs_per_rate\": [%d, %d, %d, %d]",
+           "\"leaked_fraction\": %.4f, \"avg_iterations\": %.2f, \"alice_encode_ms\": %.3f, \"epochs_per_rate\": [%d, %d, %d, %d], \"failed_per_rate\": [%d, %d, %d, %d], "
+           "\"at_max_iterations_per_rate\": [%d, %d, %d, %d]",
            epochs, key_bits, qmin, qmax, (unsigned long long)seed, batch, layered ? "layered" : "flooding", good, epochs, mean * 1e3, best * 1e3,
            (double)good * key_bits / mean / 1e6, (double)good * key_bits / best / 1e6, (double)leaked / fmax(1.0, (double)good * key_bits), it_sum / epochs,
-           t_enc * 1e3, per_rate[0], per_rate[1], per_rate[2], per_rate[3]);
+           t_enc * 1e3, per_rate[0], per_rate[1], per_rate[2], per_rate[3], fail_rate[0], fail_rate[1], fail_rate[2], fail_rate[3], maxed[0], maxed[1], maxed[2], maxed[3]);
     if (profile) {
         qldpc_kernel_stat st[16];
         qldpc_recon_profile_enable(rb, 1);
