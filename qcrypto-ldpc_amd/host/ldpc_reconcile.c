@@ -251,15 +251,37 @@ static int ldpc_fallbackStartBinSearch(ProcessBlock *pb, char *receivebuf)
     return errorCode;
 }
 
+/* LDPC packets that are still on the wire when a block goes over to cascade (the later fragments of a parity message whose first
+ * fragment was refused or malformed, a repeated verdict) must not end in ecd2.c:505-510's "subtype outside the manager's range"
+ * (error 45): the fallback tables run on to subtype 10 and drop them */
+static int ldpc_ignoreStraggler(ProcessBlock *pb, char *receivebuf)
+{
+    printf("ldpc: epoch %08x: LDPC packet (subtype %u) after the block went to cascade, ignored\n", pb->startEpoch, ((EcPktHdr_Base *)receivebuf)->subtype);
+    return 0;
+}
+
 /* the cascade follower's table (definitions/algorithms/algorithms.c:80-93) with subtype 4 wrapped */
 static const PacketHandlerArray ALG_PKTHNDLRS_LDPC_FALLBACK_FOLLOWER = {
     ldpc_fallbackStartBinSearch,            /* subtype 4 */
     cascade_followerBob_processBinSearch,   /* subtype 5 */
     cascade_generateBiconfReply,            /* subtype 6 */
     cascade_receiveBiconfReply,             /* subtype 7 */
-    privAmp_receivePrivAmpMsg               /* subtype 8 */
+    privAmp_receivePrivAmpMsg,              /* subtype 8 */
+    ldpc_ignoreStraggler,                   /* subtype 9 */
+    ldpc_ignoreStraggler                    /* subtype 10 */
 };
-static const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER = { &ALG_PKTHNDLRS_LDPC_FALLBACK_FOLLOWER, SUBTYPE_CASCADE_PARITY_LIST, SUBTYPE_START_PRIV_AMP, False };
+static const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER = { &ALG_PKTHNDLRS_LDPC_FALLBACK_FOLLOWER, SUBTYPE_CASCADE_PARITY_LIST, SUBTYPE_LDPC_VERDICT, False };
+/* the cascade initiator's table (algorithms.c:62-68), likewise */
+static const PacketHandlerArray ALG_PKTHNDLRS_LDPC_FALLBACK_INITIATOR = {
+    cascade_startBinSearch,                     /* subtype 4 */
+    cascade_initiatorAlice_processBinSearch,    /* subtype 5 */
+    cascade_generateBiconfReply,                /* subtype 6 */
+    cascade_receiveBiconfReply,                 /* subtype 7 */
+    privAmp_receivePrivAmpMsg,                  /* subtype 8 */
+    ldpc_ignoreStraggler,                       /* subtype 9 */
+    ldpc_ignoreStraggler                        /* subtype 10 */
+};
+static const ALGORITHM_PKT_MNGR ALG_PKT_MNGR_LDPC_FALLBACK_INITIATOR = { &ALG_PKTHNDLRS_LDPC_FALLBACK_INITIATOR, SUBTYPE_CASCADE_PARITY_LIST, SUBTYPE_LDPC_VERDICT, False };
 
 static int ldpc_fallBackToCascade(ProcessBlock *pb, PROCESSOR_ROLE role)
 {
@@ -267,7 +289,7 @@ static int ldpc_fallBackToCascade(ProcessBlock *pb, PROCESSOR_ROLE role)
     int errorCode, i;
     if ((errorCode = pb->algorithmDataMngr->freeData(pb))) return errorCode;
     pb->processorRole = role;
-    pb->algorithmPktMngr = (ALGORITHM_PKT_MNGR *)(role == PROC_ROLE_EC_INITIATOR ? &ALG_PKT_MNGR_CASCADE_INITIATOR : &ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER);
+    pb->algorithmPktMngr = (ALGORITHM_PKT_MNGR *)(role == PROC_ROLE_EC_INITIATOR ? &ALG_PKT_MNGR_LDPC_FALLBACK_INITIATOR : &ALG_PKT_MNGR_LDPC_FALLBACK_FOLLOWER);
     pb->algorithmDataMngr = (ALGORITHM_DATA_MNGR *)&ALG_DATA_MNGR_CASCADE;
     if ((errorCode = pb->algorithmDataMngr->initData(pb))) return errorCode;
     ldpc_normaliseMarkers(pb);
@@ -622,7 +644,7 @@ static int ldpc_flush(void)
             if (e && !errorCode) errorCode = e;
         }
     }
-    if (ldpc_batchSize() > 1 && decodedBlocks) printf("ldpc: decoded a batch of %d blocks in one call\n", decodedBlocks);
+    if (ldpc_batchSize() > 1 && decodedBlocks) { printf("ldpc: decoded a batch of %d blocks in one call\n", decodedBlocks); fflush(stdout); }
     return errorCode;
 }
 

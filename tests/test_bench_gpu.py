@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames", "256", "--n", "8192", "--k", "6554",
-                        "--n-ite", "12"], capture_output=True, text=True, timeout=600)
+                        "--n-ite", "12", "--fer-frames", "8192"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -29,13 +29,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_oracle_on_sample"] is True
     assert d["value"] > 0 and d["fer"] < 0.5
     assert d["int8_messages"]["fixed"]["value"] > 0 and d["fp16_messages"]["fixed"]["value"] > 0
+    assert "parity unpinned against AFF3CT" in d["parity_note"]
 
 
 @pytest.mark.gpu
 def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one():
     """one default run puts BASELINE configs 2 (the line itself), 3 and 5 in front of the driver, each with its own roofline,
     moved bytes beside algorithmic bytes, and no fraction above 1 (round 1's layered mode summed one pass three times)."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 4096
@@ -50,5 +51,15 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one()
     c3, c5 = d["config3_multirate_stream"], d["config5_layered_1e6"]
     assert c3["value"] > 0 and c3["fer"] <= 0.01 and 0.25 < c3["leaked_fraction"] < 0.33 and sum(c3["epochs_per_rate"].values()) == 512
     assert c5["early_exit"]["value"] > c5["fixed"]["value"] > 0 and c5["early_exit"]["avg_sweeps"] < 10 and c5["fixed"]["fer"] == 0.0
+    assert c3["undetected_errors"] == 0 and 0.0 < c3["wall_frac"] <= 1.0 and c3["value"] > 1200
+    # the FER half of the metric: >= 2^20 frames at the headline QBER with undetected errors counted, plus the waterfall
+    fd = d["fer_deep"]
+    h = fd["headline_qber"]
+    assert h["frames"] >= 1 << 20 and h["qber"] == 0.02 and h["undetected_errors"] == 0 and h["frame_errors"] <= 2
+    assert 0.0 < h["fer_upper_95"] < 1e-5 and 9 < h["avg_iterations"] < 14 and h["max_iterations"] <= 50
+    wf = fd["waterfall_seeded_shuffle"]
+    assert len(wf) == 8 and all(p_["frames"] == 65536 and p_["undetected_errors"] == 0 for p_ in wf)
+    assert wf[0]["fer"] < 0.01 < wf[3]["fer"]              # NMS: clean at 2.5 %, inside the waterfall at 3.25 %
+    assert wf[4]["fer"] < wf[0]["fer"] + 1e-3 and wf[7]["fer"] < wf[3]["fer"]      # SPA is the better rule at every point
     fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["frac"], c5["early_exit"]["roofline"]["frac"]]
     assert all(0.0 < f <= 1.0 for f in fracs), fracs

@@ -256,6 +256,10 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
         assert ref_a["nbits"] == fa["nbits"] and (ref_a["words"] == fa["words"]).all()
     expect("batched_ingest.nbits", [int(bat["finals"][st][0]["nbits"]) for st in sorted(bat["finals"])])
     batches = [int(x) for x in re.findall(r"decoded a batch of (\d+) blocks in one call", bat["b_log"])]
+    if sum(batches) != 8:      # keep the daemons' logs where gpurun brings them back
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        for side in "ab":
+            open(os.path.join(ROOT, "gpurun_out", "ecd2_batch_%s.log" % side), "w").write(bat[side + "_log"])
     assert sum(batches) == 8 and max(batches) >= 2, batches
     assert "decoded a batch" not in one["b_log"]
 
@@ -398,7 +402,9 @@ def test_initiator_without_a_plan_tells_the_follower_and_both_use_cascade(tmp_pa
     "unsupported": she must send the no-plan header, the follower answers with a failed verdict, and the block is reconciled by
     cascade in the same daemons."""
     binary = need("ecd2_ldpc")
-    a, b = epochs(43, 4, 5003, 0.03)
+    # (inputs the reference's cascade reconciles with its FIXED seed: with every seed the same constant its BICONF rounds repeat their
+    #  subsets, and the pristine daemon leaves residual errors on some inputs -- e.g. epochs(48, 4, 9001, 0.02), or these at 3 %)
+    a, b = epochs(43, 4, 5003, 0.02)
     out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1"], extra_args_a=["-L", "1,n1"], timeout=90)
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
     assert "telling the follower" in out["a_log"] and "the initiator has no code for this block" in out["b_log"]
@@ -412,8 +418,9 @@ def test_malformed_parity_fragment_gets_a_failed_verdict(tmp_path):
     """a fragment whose word offset does not match its index (`-L z1`: Alice shifts the offset of fragment 1) is not placed
     anywhere; the follower says so, answers with a failed verdict and the block goes to cascade instead of stalling both daemons."""
     binary = need("ecd2_ldpc")
-    a, b = epochs(47, 4, 9001, 0.04)
-    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1,p1000"], extra_args_a=["-L", "1,p1000,z1"], timeout=90)
+    a, b = epochs(47, 4, 9001, 0.02)      # (an input the fixed-seed cascade reconciles, see the test above; <= 500-byte packets: the parity travels in fragments)
+    out = run_loopback(binary, tmp_path, a, b, extra_args=["-L", "1,p500"], extra_args_a=["-L", "1,p500,z1"], timeout=90)
+    assert int(re.search(r"sent parity in (\d+) packet", out["a_log"]).group(1)) >= 2
     assert out["a_final"] is not None and out["b_final"] is not None, out["a_log"][-2000:] + "\n----\n" + out["b_log"][-2000:]
     assert "malformed parity packet" in out["b_log"] and "falling back to cascade as EC follower" in out["b_log"]
     assert out["a_final"]["nbits"] == out["b_final"]["nbits"] and (out["a_final"]["words"] == out["b_final"]["words"]).all()
