@@ -25,6 +25,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# PEG-built codes (the sessions' mother codes, the second code of the FER leg) are kept as checksummed edge lists here, so that Alice's and
+# Bob's sessions of the config-3 leg build each code once (construction is outside every timed region either way)
+import tempfile  # noqa: E402
+
+os.environ.setdefault("QLDPC_CODE_CACHE", os.path.join(tempfile.gettempdir(), "qldpc_code_cache_%d" % os.getuid()))
+os.makedirs(os.environ["QLDPC_CODE_CACHE"], exist_ok=True)
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -405,7 +412,7 @@ def main():
 
     # ---- BASELINE config 3: multi-rate H set {0.5, 0.7, 0.8, 0.9} chosen per epoch from the estimated QBER, a stream of epochs through
     #      the reconciliation sessions (what the ecd2 handlers call), HOST buffers in and out ----------------------------------------
-    def config3(peg_depth=0, rate_gap=None):
+    def config3(peg_depth=2, rate_gap=None):
         epochs_n, key_bits, batch = 512, 52429, 256      # the daemon's batched ingest (-L b<n>)
         rng = np.random.default_rng(42)
         qbers = rng.uniform(0.005, 0.06, epochs_n).astype(np.float32)
@@ -482,9 +489,9 @@ def main():
             cfg5["at_256_frames"] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"]}
                                      for k_ in ("fixed", "early_exit")}
         if not args.no_config3:
-            cfg3 = config3()
-            if args.peg > 0:      # the same stream on PEG-built mother codes, planned closer to capacity (sessions' peg_depth)
-                cfg3["peg_mothers"] = config3(peg_depth=args.peg)
+            cfg3 = config3()      # the sessions' default: PEG-built mother codes (depth 2)
+            shuf = config3(peg_depth=0, rate_gap=0.035)      # round 2's codes and gap: the seeded socket shuffle, for comparison
+            cfg3["seeded_shuffle_mothers"] = {k_: shuf[k_] for k_ in ("value", "fer", "fer_after_second_round", "leaked_fraction", "ms_total", "avg_iterations", "wall_frac", "workload")}
         if not args.no_fer_deep:
             ferd = fer_deep()
 

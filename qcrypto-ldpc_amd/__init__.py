@@ -574,7 +574,7 @@ class Recon:
 
     def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=None, rule=None, rule_param=None,
                  key_quantum=1024, max_blocks=1, seed=7, schedule="flooding", mother_step=None, mother_max=None, rate_gap=None,
-                 puncture=True, preload=False, peg_depth=0):
+                 puncture=True, preload=False, peg_depth=None):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
         cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
@@ -592,7 +592,9 @@ class Recon:
             cfg.mother_max = int(mother_max)
         if rate_gap is not None:
             cfg.rate_gap = float(rate_gap)
-        cfg.puncture, cfg.preload, cfg.peg_depth = (1 if puncture else 2), int(bool(preload)), int(peg_depth)
+        cfg.puncture, cfg.preload = (1 if puncture else 2), int(bool(preload))
+        if peg_depth is not None:      # library default: 2 (mother codes by progressive edge growth)
+            cfg.peg_depth = int(peg_depth)
         h = _vp()
         _chk(_L.qldpc_recon_create(C.byref(cfg), C.byref(h)), "Recon")
         self._h = h

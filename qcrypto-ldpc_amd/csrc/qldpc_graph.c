@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stddef.h>
+#include <unistd.h>
 
 /* ------------------------------------------------------------------ errors ------------------- */
 
@@ -553,7 +555,94 @@ static int ivec_push(ivec *v, int x)
     return 0;
 }
 
+/*
+ * Edge-list cache on disk.  Progressive edge growth is deterministic in (N, K, profile, depth, seed) but takes 0.1 - 10 s per code
+ * (the depth-2 search through the degree-38 checks of a rate-0.9 mother is the slow case), and the daemon builds 32 mother codes in
+ * ldpc_init: with QLDPC_CODE_CACHE=<directory> in the environment a code is built once, its edge list written there
+ * (<dir>/ira_peg_N.._K.._h.._dv.._.._d.._s...edges: header, var[E], chk[E], FNV-1a checksum; written to a temporary name and renamed) and
+ * read back on every later start after its header and checksum have been verified -- a file that fails either is ignored and rebuilt.
+ * Alice and Bob need not share the directory: both derive the same code from the same parameters.
+ */
+static uint64_t fnv1a64(const void *data, size_t n, uint64_t h)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+#define PEG_CACHE_MAGIC 0x3147444551444c51ull      /* "QLDQEDG1" */
+typedef struct { uint64_t magic; int32_t N, K, dv_hi, dv_lo, depth, E; uint32_t hi_frac_bits; uint64_t seed; } peg_cache_hdr;
+
+static int peg_cache_path(char *buf, size_t cap, int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed)
+{
+    const char *dir = getenv("QLDPC_CODE_CACHE");
+    if (!dir || !*dir) return 0;
+    const int n = snprintf(buf, cap, "%s/ira_peg_N%d_K%d_h%.6f_dv%d_%d_d%d_s%llu.edges", dir, N, K, (double)hi_frac, dv_hi, dv_lo, depth, (unsigned long long)seed);
+    return n > 0 && (size_t)n < cap;
+}
+
+static int peg_cache_load(const char *path, const peg_cache_hdr *want, qldpc_code **out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return 0;
+    peg_cache_hdr h;
+    int ok = 0, *var = NULL, *chk = NULL;
+    uint64_t sum = 0;
+    if (fread(&h, sizeof(h), 1, f) == 1 && !memcmp(&h, want, offsetof(peg_cache_hdr, E)) && h.hi_frac_bits == want->hi_frac_bits && h.seed == want->seed &&
+        h.E > 0 && h.E < (1 << 28)) {
+        var = (int *)malloc(sizeof(int) * (size_t)h.E); chk = (int *)malloc(sizeof(int) * (size_t)h.E);
+        if (var && chk && fread(var, sizeof(int), (size_t)h.E, f) == (size_t)h.E && fread(chk, sizeof(int), (size_t)h.E, f) == (size_t)h.E && fread(&sum, sizeof(sum), 1, f) == 1) {
+            uint64_t s2 = fnv1a64(&h, sizeof(h), 0xcbf29ce484222325ull);
+            s2 = fnv1a64(var, sizeof(int) * (size_t)h.E, s2);
+            s2 = fnv1a64(chk, sizeof(int) * (size_t)h.E, s2);
+            ok = s2 == sum;
+            for (int e = 0; ok && e < h.E; e++) ok = var[e] >= 0 && var[e] < h.N && chk[e] >= 0 && chk[e] < h.N - h.K;
+            if (ok) ok = qldpc_code_from_edges(h.N, h.N - h.K, h.E, var, chk, out) == QLDPC_OK;
+        }
+    }
+    fclose(f);
+    free(var); free(chk);
+    return ok;
+}
+
+static void peg_cache_store(const char *path, peg_cache_hdr *h, const qldpc_code *code)
+{
+    char tmp[1100];
+    if (snprintf(tmp, sizeof(tmp), "%s.tmp%ld", path, (long)getpid()) >= (int)sizeof(tmp)) return;
+    int *chk = (int *)malloc(sizeof(int) * (size_t)code->E);
+    FILE *f = chk ? fopen(tmp, "wb") : NULL;
+    if (f) {
+        for (int c = 0; c < code->M; c++) for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) chk[k] = c;
+        h->E = code->E;
+        uint64_t sum = fnv1a64(h, sizeof(*h), 0xcbf29ce484222325ull);
+        sum = fnv1a64(code->cn_var, sizeof(int) * (size_t)code->E, sum);
+        sum = fnv1a64(chk, sizeof(int) * (size_t)code->E, sum);
+        const int ok = fwrite(h, sizeof(*h), 1, f) == 1 && fwrite(code->cn_var, sizeof(int), (size_t)code->E, f) == (size_t)code->E &&
+                       fwrite(chk, sizeof(int), (size_t)code->E, f) == (size_t)code->E && fwrite(&sum, sizeof(sum), 1, f) == 1;
+        if (fclose(f) == 0 && ok) { if (rename(tmp, path) != 0) remove(tmp); }
+        else remove(tmp);
+    }
+    free(chk);
+}
+
+static int ira_peg_build(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out);
+
 int qldpc_code_ira_peg(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out)
+{
+    char path[1024];
+    peg_cache_hdr h;
+    if (!out) return QLDPC_EINVAL;
+    *out = NULL;
+    memset(&h, 0, sizeof(h));
+    h.magic = PEG_CACHE_MAGIC; h.N = N; h.K = K; h.dv_hi = dv_hi; h.dv_lo = dv_lo; h.depth = depth; h.seed = seed;
+    memcpy(&h.hi_frac_bits, &hi_frac, sizeof(h.hi_frac_bits));
+    const int cached = peg_cache_path(path, sizeof(path), N, K, hi_frac, dv_hi, dv_lo, depth, seed);
+    if (cached && peg_cache_load(path, &h, out)) return QLDPC_OK;
+    const int rc = ira_peg_build(N, K, hi_frac, dv_hi, dv_lo, depth, seed, out);
+    if (rc == QLDPC_OK && cached) peg_cache_store(path, &h, *out);
+    return rc;
+}
+
+static int ira_peg_build(int N, int K, float hi_frac, int dv_hi, int dv_lo, int depth, uint64_t seed, qldpc_code **out)
 {
     if (!out) return QLDPC_EINVAL;
     *out = NULL;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cmath>
@@ -261,7 +262,7 @@ extern "C" void qldpc_recon_cfg_default(qldpc_recon_cfg *c)
     c->rate_gap = 0.0f;             /* 0 = by rule: 0.03 for SPA, 0.05 for the min-sum family */
     c->puncture = 1;
     c->preload = 0;
-    c->peg_depth = 0;
+    c->peg_depth = 2;               /* mother codes by progressive edge growth, no 4-cycles */
 }
 
 /*
@@ -370,7 +371,8 @@ static void code_dims(const qldpc_recon_cfg &c, int key_bits, double R, int *K, 
     *K = k; *M = m;
 }
 
-static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out);
+static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out, qldpc_code *prebuilt = nullptr);
+static int build_code(const qldpc_recon_cfg &cfg, int K, int M, qldpc_code **out);
 static void cache_trim(qldpc_recon *r)
 {
     if (r->cache.size() <= r->keep) return;
@@ -426,14 +428,44 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     if (cfg->preload && mothers) {
         /* every (mother size, table rate) pair now: code, encoder, decoder and staging buffers, so that no block of up to mother_max
          * bits builds a code or allocates device memory later (the daemon calls this from ldpc_init) */
+        struct todo { int K, M; qldpc_code *code; int rc; std::string err; };
+        std::vector<todo> list;
         for (int k = cfg->mother_step; k <= cfg->mother_max; k += cfg->mother_step)
             for (int i = 0; i < cfg->n_rates; i++) {
-                int K, M;
-                code_dims(r->cfg, k, cfg->rates[i], &K, &M);
-                recon_entry *e;
-                const int rc = get_entry(r, K, M, &e);
-                if (rc) { qldpc_recon_free(r); return rc; }
+                todo t;
+                code_dims(r->cfg, k, cfg->rates[i], &t.K, &t.M);
+                t.code = nullptr; t.rc = QLDPC_OK;
+                list.push_back(t);
             }
+        /* the codes are host work (progressive edge growth: 0.1 - 10 s each unless QLDPC_CODE_CACHE holds them): built side by side on
+         * the host's cores, largest first; the device objects follow one by one */
+        std::vector<size_t> order(list.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return (double)list[a].K / list[a].M * list[a].K > (double)list[b].K / list[b].M * list[b].K; });
+        std::atomic<size_t> next(0);
+        auto worker = [&]() {
+            for (size_t at = next++; at < order.size(); at = next++) {
+                todo &t = list[order[at]];
+                t.rc = build_code(r->cfg, t.K, t.M, &t.code);
+                if (t.rc) t.err = qldpc_last_error();
+            }
+        };
+        unsigned nthreads = std::thread::hardware_concurrency();
+        if (const char *env = getenv("QLDPC_BUILD_THREADS")) nthreads = (unsigned)atoi(env);
+        nthreads = std::max(1u, std::min(nthreads, std::min(16u, (unsigned)list.size())));
+        if (cfg->peg_depth <= 0) nthreads = 1;      /* the seeded shuffle takes milliseconds */
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthreads; t++) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+        int rc = QLDPC_OK;
+        for (auto &t : list) if (t.rc && !rc) { rc = t.rc; qldpc_set_error("%s", t.err.c_str()); }
+        for (auto &t : list) {
+            if (rc) { qldpc_code_free(t.code); continue; }
+            recon_entry *e;
+            rc = get_entry(r, t.K, t.M, &e, t.code);      /* takes the code over (also on failure: entry_free) */
+        }
+        if (rc) { qldpc_recon_free(r); return rc; }
     }
     *out = r;
     return QLDPC_OK;
@@ -481,6 +513,33 @@ extern "C" int qldpc_recon_profile_read(qldpc_recon *r, qldpc_kernel_stat *out, 
 #define RECON_PUNCT_CAP 0.65
 static float clamp_qber(float q) { return !(q > 0.001f) ? 0.001f : (q > 0.25f ? 0.25f : q); }
 
+/*
+ * c(R): how much of rate_gap a mother code of rate R needs.  Calibrated on streams of 2 048 epochs x 52 429 bits, QBER ~ U[0.5 %, 6 %], two
+ * seeds each (qldpc_stream -e 2048 -P <depth>, QLDPC_RECON_GAP_SCALE; logs: profiles/r03_gap_calibration.txt):
+ *   PEG-built mothers (peg_depth > 0)   0.10 (mothers of K >= 32 768; more below) / 0.85 / 1.0   for R <= 0.75 / <= 0.85 / above: 0 - 1 first-round failures in 2 048 epochs, leak 0.2896 of
+ *                                       the key (the configured efficiency f = 1.4 alone gives 0.288); the low-rate mothers decode to within
+ *                                       0.004 of capacity, the rate-0.8 / 0.9 mothers need their 0.03 (0.025: 2 - 4 % failures)
+ *   seeded-shuffle mothers (round 2)    0.60 / 0.90 / 1.0   (0.85 for the middle value: 39 failures of 918 on one seed where PEG has none)
+ * QLDPC_RECON_GAP_SCALE="lo,mid,hi" overrides the three values for calibration runs -- both sides must then use the same.
+ */
+static double gap_scale(const qldpc_recon_cfg &cfg, double R, int K)
+{
+    static double env[3] = {-2.0, 0.0, 0.0};
+    if (env[0] < -1.5) {
+        double v[3] = {-1.0, -1.0, -1.0};
+        if (const char *e = getenv("QLDPC_RECON_GAP_SCALE")) (void)sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);
+        env[1] = v[1]; env[2] = v[2]; env[0] = v[0];
+    }
+    const int k = R <= 0.75 ? 0 : (R <= 0.85 ? 1 : 2);
+    if (env[0] >= 0.0 && env[k] >= 0.0) return env[k];
+    static const double peg[3] = {0.10, 0.85, 1.0}, shuffle[3] = {0.60, 0.90, 1.0};
+    if (cfg.peg_depth <= 0) return shuffle[k];
+    /* short low-rate mothers need more room: 0.1 from K = 32 768 upwards, 0.25 at 16 384, 0.6 at 8 192 (7 000-bit blocks: 24 failures of
+     * 1 203 at rate 0.7 with 0.1 - 0.3, 1 with 0.6; 15 000-bit blocks: 1 - 2 of 1 100 at any value) */
+    if (k == 0) return std::min(0.6, std::max(0.10, 0.10 * pow(32768.0 / (double)K, 1.3)));
+    return peg[k];
+}
+
 extern "C" int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, qldpc_recon_msg *msg)
 {
     if (!r || !msg) return QLDPC_EINVAL;
@@ -500,7 +559,7 @@ extern "C" int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, 
     double need = 0.0;
     for (int i = 0; i < r->cfg.n_rates; i++) {
         const double R = r->cfg.rates[i];
-        const double gap = gap_len * (R <= 0.75 ? 0.6 : (R <= 0.85 ? 0.9 : 1.0));
+        const double gap = gap_len * gap_scale(r->cfg, R, K0);
         double t = qldpc_min_code_rate(q, r->cfg.efficiency);
         if (1.0 - h - gap < t) t = 1.0 - h - gap;
         if (R <= t) { idx = i; need = t; }
@@ -524,7 +583,15 @@ extern "C" int qldpc_recon_plan(const qldpc_recon *r, int key_bits, float qber, 
     return QLDPC_OK;
 }
 
-static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
+/* the code of an entry: DVB-like IRA profile (12.5 % of the information VNs of degree 11, the rest 3), information part by the seeded socket
+ * shuffle or by progressive edge growth (peg_depth); both sides derive the same code from (K, M, peg_depth, seed) */
+static int build_code(const qldpc_recon_cfg &cfg, int K, int M, qldpc_code **out)
+{
+    const int N = K + M;
+    return cfg.peg_depth > 0 ? qldpc_code_ira_peg(N, K, 0.125f, 11, 3, cfg.peg_depth, cfg.seed, out) : qldpc_code_ira(N, K, 0.125f, 11, 3, cfg.seed, out);
+}
+
+static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out, qldpc_code *prebuilt)
 {
     for (auto it = r->cache.begin(); it != r->cache.end(); ++it)
         if (it->K == K && it->M == M) { r->cache.splice(r->cache.begin(), r->cache, it); *out = &r->cache.front(); return QLDPC_OK; }
@@ -532,7 +599,9 @@ static int get_entry(qldpc_recon *r, int K, int M, recon_entry **out)
     memset(&e, 0, sizeof(e));
     e.K = K; e.M = M;
     const int N = K + M, Wk = K / 32, Wn = (N + 31) / 32, Wm = (M + 31) / 32, B = r->cfg.max_blocks;
-    int rc = r->cfg.peg_depth > 0 ? qldpc_code_ira_peg(N, K, 0.125f, 11, 3, r->cfg.peg_depth, r->cfg.seed, &e.code) : qldpc_code_ira(N, K, 0.125f, 11, 3, r->cfg.seed, &e.code);
+    int rc = QLDPC_OK;
+    if (prebuilt) e.code = prebuilt;
+    else rc = build_code(r->cfg, K, M, &e.code);
     if (!rc) rc = qldpc_encoder_create(e.code, "IRA", r->cfg.device, &e.enc);
     if (!rc) rc = qldpc_encoder_reserve(e.enc, B);      /* nothing is allocated per block later */
     if (!rc) {

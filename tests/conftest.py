@@ -9,6 +9,14 @@ if ROOT not in sys.path:
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
+# The sessions' mother codes are grown by progressive edge growth (0.1 - 10 s each); libqldpc keeps their edge lists in this directory
+# (QLDPC_CODE_CACHE, checksummed files) so that the suite -- dozens of sessions, two daemons per loopback, 32 codes per daemon -- builds
+# each code once.  tests/test_host.py checks that a cached code is the built code and that a damaged file is rebuilt.
+import tempfile  # noqa: E402
+
+os.environ.setdefault("QLDPC_CODE_CACHE", os.path.join(tempfile.gettempdir(), "qldpc_code_cache_%d" % os.getuid()))
+os.makedirs(os.environ["QLDPC_CODE_CACHE"], exist_ok=True)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

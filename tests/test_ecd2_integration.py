@@ -26,6 +26,13 @@ GOLD_PATH = os.path.join(ROOT, "tests", "golden", "ecd2_expected.json")
 GOLD = json.load(open(GOLD_PATH)) if os.path.exists(GOLD_PATH) else {}
 
 
+@pytest.fixture(scope="module")
+def warm_code_cache(q):
+    """the daemons build 32 PEG mother codes in ldpc_init; one preloading session fills QLDPC_CODE_CACHE (tests/conftest.py) first, so that
+    every daemon of this module reads them back in milliseconds instead of two daemons growing them side by side in every test"""
+    q.Recon(preload=True)
+
+
 def expect(key, value):
     if os.environ.get("ECD2_RECORD"):
         path = os.path.join(ROOT, "gpurun_out", "ecd2_observed.json")
@@ -97,7 +104,7 @@ def test_reference_cascade_loopback_is_the_integration_oracle(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_epochs,bits,qber", [(4, 4001, 0.02), (4, 15001, 0.02), (2, 9000, 0.03)])
-def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
+def test_ldpc_handlers_inside_ecd2(warm_code_cache, tmp_path, n_epochs, bits, qber):
     """`-L 1` (ecd2's new option): Bob (QBER follower) picks ALG_LDPC_CONTINUE_ROLES; one parity packet + one verdict instead of
     ~55 cascade packets each way; both daemons write identical final keys."""
     binary = need("ecd2_ldpc")
@@ -129,7 +136,7 @@ def test_ldpc_handlers_inside_ecd2(tmp_path, n_epochs, bits, qber):
 
 
 @pytest.mark.gpu
-def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
+def test_full_size_block_ldpc_plus_gpu_privacy_amplification(warm_code_cache, tmp_path):
     """4 epochs x 15 000 bits (the block of SURVEY.md section 4 / 6): LDPC reconciliation and the PA hash both on the GPU.
     Alice hashes on her GPU, Bob on his: equal stream-7 files prove the GPU hash equals itself across processes AND,
     through the CPU run below with the SAME daemons, that it is the reference's hash."""
@@ -176,7 +183,7 @@ def test_full_size_block_ldpc_plus_gpu_privacy_amplification(tmp_path):
 
 
 @pytest.mark.gpu
-def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
+def test_ldpc_and_cascade_daemons_agree_on_key_length_order(warm_code_cache, tmp_path):
     """same epochs through both daemons: both reconcile; LDPC leaks M+32 bits, cascade its parity count."""
     a, b = epochs(3, 4, 6001, 0.02)
     o1 = run_loopback(need("ecd2_cascade"), tmp_path / "c", a, b)
@@ -189,7 +196,7 @@ def test_ldpc_and_cascade_daemons_agree_on_key_length_order(tmp_path):
 
 
 @pytest.mark.gpu
-def test_decode_failure_falls_back_to_cascade(tmp_path):
+def test_decode_failure_falls_back_to_cascade(warm_code_cache, tmp_path):
     """SURVEY.md section 8(f)1 "fallback to cascade on decode failure": Alice's parity packet is corrupted on purpose
     (ECD2_LDPC_FAULT flips disclosed parity bits), Bob finds no verified codeword, says so in the verdict, and both
     daemons finish the block with the reference's own cascade exchange. The final keys are identical, and the wasted
@@ -221,7 +228,7 @@ def test_decode_failure_falls_back_to_cascade(tmp_path):
 
 
 @pytest.mark.gpu
-def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
+def test_batched_ingest_several_blocks_in_one_decode_call(warm_code_cache, tmp_path):
     """eight commands are written at once, so eight blocks are in flight; with ECD2_LDPC_BATCH=4 Bob
     queues the parity packets and ldpc_tick() decodes them four at a time in one qldpc_recon_decode_blocks call (blocks of
     different length share a plan).  Every block ends with identical keys on both sides, equal to what the unbatched
@@ -265,7 +272,7 @@ def test_batched_ingest_several_blocks_in_one_decode_call(tmp_path):
 
 
 @pytest.mark.gpu
-def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
+def test_block_above_65536_bits_with_fragmented_parity(warm_code_cache, tmp_path):
     """SURVEY.md 8f #4 second half / VERDICT r1 #4a, #8: two 60 001-bit epochs are loaded as ONE block of 120 002 bits (the LDPC build
     raises MAX_BITS_PER_PROCESSBLOCK, processblock_mgmt.c:94-95; cascade with its unsigned short indices could not take it), at
     QBER 4.5 % the plan discloses 42 000 - 50 000 parity bits; `-L p3000` makes every parity packet at most 3 000 bytes so the
@@ -284,7 +291,7 @@ def test_block_above_65536_bits_with_fragmented_parity(tmp_path):
 
 
 @pytest.mark.gpu
-def test_sample_without_errors_and_repeated_parity_packets(tmp_path):
+def test_sample_without_errors_and_repeated_parity_packets(warm_code_cache, tmp_path):
     """(1) identical keys -> the QBER sample has no error, localError = 0 (qber_estim.c:26); the plan clamps it instead
     of refusing, the block reconciles (nothing to correct) and yields a key.  (2) a parity packet that arrives twice (`-L d1`
     makes Alice send every parity packet twice) must not queue the block twice: with the batched ingest the second copy used to
@@ -306,7 +313,7 @@ def test_sample_without_errors_and_repeated_parity_packets(tmp_path):
 
 
 @pytest.mark.gpu
-def test_refused_parity_header_gets_a_failed_verdict_and_the_block_falls_back(tmp_path):
+def test_refused_parity_header_gets_a_failed_verdict_and_the_block_falls_back(warm_code_cache, tmp_path):
     """a parity header that is not what the follower's own rate table gives for the block (`-L y1`: Alice claims the next
     rate index with the dimensions of the real one) is refused BEFORE anything is allocated for its payload, answered with a failed
     verdict -- the initiator is not left waiting -- and the block is reconciled by cascade in the same daemons."""
@@ -321,7 +328,7 @@ def test_refused_parity_header_gets_a_failed_verdict_and_the_block_falls_back(tm
 
 
 @pytest.mark.gpu
-def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
+def test_planning_margin_discloses_more_and_still_reconciles(warm_code_cache, tmp_path):
     """`-L m<n>` on the initiator: the code is planned for q + n/10 sigma of the sampled estimate (short blocks: the estimate is noisy and
     the plan sits 0.02 - 0.05 from capacity).  More parity bits go out, the header carries the plan, the follower needs no option."""
     binary = need("ecd2_ldpc")
@@ -345,7 +352,7 @@ def test_planning_margin_discloses_more_and_still_reconciles(tmp_path):
 
 
 @pytest.mark.gpu
-def test_block_beyond_the_rate_table_goes_to_cascade_from_the_start(tmp_path):
+def test_block_beyond_the_rate_table_goes_to_cascade_from_the_start(warm_code_cache, tmp_path):
     """The rate table ends at 0.5: for an estimated QBER of about 10.5 % and more the plan has no code, and the reference itself ends blocks
     at 15 % (USELESS_ERRORBOUND, qber_estim.c:28-31).  In between, the QBER follower's per-block choice (`ldpc_selectedFor`) hands the block
     to cascade instead of ending the daemon with error 88; the next block, at 2 %, is LDPC again in the same daemon pair.  Each run draws
@@ -373,7 +380,7 @@ def test_block_beyond_the_rate_table_goes_to_cascade_from_the_start(tmp_path):
 
 
 @pytest.mark.gpu
-def test_failed_first_decode_gets_the_withheld_parity_bits_instead_of_cascade(tmp_path):
+def test_failed_first_decode_gets_the_withheld_parity_bits_instead_of_cascade(warm_code_cache, tmp_path):
     """Second round (incremental redundancy): Alice's first parity message is corrupted (`-L x600`), Bob finds no verified codeword and
     answers with verdict 2; Alice sends the parity bits her plan had punctured (the whole parity of the same codeword, header nPunct = 0),
     Bob decodes at the mother code's rate.  One more packet instead of the cascade exchange; the block's leak is M + 32 bits."""
@@ -396,7 +403,7 @@ def test_failed_first_decode_gets_the_withheld_parity_bits_instead_of_cascade(tm
 
 
 @pytest.mark.gpu
-def test_initiator_without_a_plan_tells_the_follower_and_both_use_cascade(tmp_path):
+def test_initiator_without_a_plan_tells_the_follower_and_both_use_cascade(warm_code_cache, tmp_path):
     """the main loop drops a handler's return value (ecd2.c:524), so `return LDPC_ERR_RATE` from an initiator that has no code
     for a block the follower chose LDPC for used to leave both daemons waiting.  `-L n1` (test hook) makes Alice's plan come back
     "unsupported": she must send the no-plan header, the follower answers with a failed verdict, and the block is reconciled by
@@ -414,7 +421,7 @@ def test_initiator_without_a_plan_tells_the_follower_and_both_use_cascade(tmp_pa
 
 
 @pytest.mark.gpu
-def test_malformed_parity_fragment_gets_a_failed_verdict(tmp_path):
+def test_malformed_parity_fragment_gets_a_failed_verdict(warm_code_cache, tmp_path):
     """a fragment whose word offset does not match its index (`-L z1`: Alice shifts the offset of fragment 1) is not placed
     anywhere; the follower says so, answers with a failed verdict and the block goes to cascade instead of stalling both daemons."""
     binary = need("ecd2_ldpc")

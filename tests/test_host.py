@@ -338,3 +338,27 @@ def test_chunked_crc_equals_the_bytewise_crc(q):
         assert ref == zlib.crc32(masked.astype(">u4").tobytes())
         for lanes in (1, 2, 8, 64, 256):
             assert q.crc32_words(w, nb, lanes) == ref, (nb, lanes)
+
+
+def test_peg_edge_list_cache_returns_the_built_code_and_survives_a_damaged_file(q, tmp_path, monkeypatch):
+    """QLDPC_CODE_CACHE: a PEG code is built once and read back afterwards -- the same graph edge for edge, layers included; a file whose
+    checksum fails is ignored and rebuilt; Alice and Bob (no shared directory) still derive the same code."""
+    monkeypatch.delenv("QLDPC_CODE_CACHE", raising=False)
+    ref = q.Code.ira_peg(4096 + 1024, 4096, 0.125, 11, 3, 2, 7)
+    monkeypatch.setenv("QLDPC_CODE_CACHE", str(tmp_path))
+    built = q.Code.ira_peg(4096 + 1024, 4096, 0.125, 11, 3, 2, 7)
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("ira_peg_N5120_K4096_") and files[0].suffix == ".edges"
+    cached = q.Code.ira_peg(4096 + 1024, 4096, 0.125, 11, 3, 2, 7)
+    for c in (built, cached):
+        assert (c.N, c.M, c.E, c.n_layers) == (ref.N, ref.M, ref.E, ref.n_layers)
+        for x, y in zip(c.edges(), ref.edges()):
+            assert (x == y).all()
+    raw = bytearray(files[0].read_bytes())
+    raw[len(raw) // 2] ^= 0x40
+    files[0].write_bytes(bytes(raw))
+    again = q.Code.ira_peg(4096 + 1024, 4096, 0.125, 11, 3, 2, 7)       # checksum fails -> rebuilt, and the file is whole again
+    assert all((x == y).all() for x, y in zip(again.edges(), ref.edges()))
+    assert files[0].read_bytes() != bytes(raw)
+    other = q.Code.ira_peg(4096 + 1024, 4096, 0.125, 11, 3, 2, 8)       # another seed: another file, another code
+    assert len(list(tmp_path.iterdir())) == 2 and not all((x == y).all() for x, y in zip(other.edges(), ref.edges()))

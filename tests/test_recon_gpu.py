@@ -11,7 +11,8 @@ def target_rate(q, key_bits, qber, step=8192):
     pc = min(max(qber, 0.001), 0.25)
     best = 0.0
     for R in (0.5, 0.7, 0.8, 0.9):      # the highest table rate that fits under its own target (the gap shrinks with the mother's rate)
-        gap = 0.035 * (65536.0 / K) ** 0.4 * (0.6 if R <= 0.75 else (0.9 if R <= 0.85 else 1.0))
+        c_lo = min(0.6, max(0.10, 0.10 * (32768.0 / K) ** 1.3))      # PEG-built mothers (the default): short low-rate mothers keep more room
+        gap = 0.035 * (65536.0 / K) ** 0.4 * (c_lo if R <= 0.75 else (0.85 if R <= 0.85 else 1.0))
         t = min(q.min_code_rate(pc, 1.4), 1.0 - float(q.binary_entropy(pc)) - gap)
         if R <= t:
             best = t
@@ -140,7 +141,7 @@ def test_layered_sessions_reconcile_the_same_blocks(q):
         m, par = r.encode(a, key_bits, 0.025)
         A.append(a); B.append(b); msgs.append(m); pars.append(par)
     st, fixed, co, it = r.decode_batch(np.stack(B), key_bits, np.full(12, 0.025, np.float32), msgs, pars)
-    assert (st == 0).all() and (fixed == np.stack(A)).all() and it.max() <= 20      # layered: about half the sweeps flooding needs (60 allowed)
+    assert (st == 0).all() and (fixed == np.stack(A)).all() and it.max() <= 30      # layered: about half the sweeps flooding needs (60 allowed; the PEG plans sit closer to capacity than round 2's)
 
 
 @pytest.mark.parametrize("max_blocks", [4, 16])
