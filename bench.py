@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 4096 = BASELINE config 2 on one GPU; 32768 = config 4's shard when WORLD_SIZE > 1)")
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (multi-rate stream through the reconciliation sessions)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (N = 10^6 horizontal-layered)")
+    ap.add_argument("--config5-frames", default="64,256", help="batches of the config-5 leg: SURVEY 8d's 64 frames, then (optional) a chip-filling batch")
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--k", type=int, default=52429)
     ap.add_argument("--qber", type=float, default=0.02)
@@ -484,10 +485,12 @@ def main():
     cfg3 = cfg5 = ferd = None
     if rank == 0 and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32" and (N, K) == (65536, 52429):
         if not args.no_config5:
-            cfg5 = config5()                    # batch 64 (one frame group: 6 667 waves per colour layer)
-            big = config5(256)                  # the same code with enough frames to fill the chip
-            cfg5["at_256_frames"] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"]}
-                                     for k_ in ("fixed", "early_exit")}
+            f5s = [int(x) for x in args.config5_frames.split(",") if x]
+            cfg5 = config5(f5s[0])              # batch 64 (one frame group: 6 667 waves per colour layer)
+            for f5 in f5s[1:]:                  # the same code with enough frames to fill the chip
+                big = config5(f5)
+                cfg5["at_%d_frames" % f5] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"]}
+                                             for k_ in ("fixed", "early_exit")}
         if not args.no_config3:
             cfg3 = config3()      # the sessions' default: PEG-built mother codes (depth 2)
             shuf = config3(peg_depth=0, rate_gap=0.035)      # round 2's codes and gap: the seeded socket shuffle, for comparison
@@ -521,7 +524,7 @@ def main():
     traffic, traffic_src, vn_traffic = None, None, None
     if rank == 0:
         try:
-            pmc_path = os.path.join("profiles", "r02_fixed50_pmc_hbm_traffic.json")
+            pmc_path = os.path.join("profiles", "r03_fixed50_pmc_hbm_traffic.json")
             pmc = json.load(open(os.path.join(ROOT, pmc_path)))
             w = pmc["workload"]
             fpl = args.frames_per_lane or 1
