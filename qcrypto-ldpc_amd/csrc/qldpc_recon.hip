@@ -876,11 +876,6 @@ static int run_call(qldpc_recon *r, const recon_call &call, const std::vector<ch
             if (!taken[(size_t)j] && mj.code_k == mi.code_k && mj.code_m == mi.code_m) { g.idx.push_back(j); taken[(size_t)j] = 1; }
         }
         if ((rc = get_entry(r, (int)mi.code_k, (int)mi.code_m, &g.e))) { cache_trim(r); return rc; }
-        /* Bob: a 64-frame group of the decoder runs until its slowest frame has converged, so frames that need about the same number of
-         * iterations belong together.  Within one mother code the plan leaves low-QBER blocks closest to capacity (the gap binds there, the
-         * configured efficiency further up), i.e. the iteration count falls with the QBER: order the blocks of a group by it. */
-        if (call.bob && !getenv("QLDPC_RECON_NOSORT"))
-            std::stable_sort(g.idx.begin(), g.idx.end(), [&](int a, int b) { return call.qber[a] < call.qber[b]; });
         g.cost = (double)g.idx.size() * (double)(mi.code_k + mi.code_m);
         groups.push_back(std::move(g));
     }
