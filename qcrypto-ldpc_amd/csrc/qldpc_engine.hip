@@ -894,7 +894,7 @@ template <int S, int FAM>
 static int launch_persist(qldpc_decoder *d)
 {
     const void *fn = (const void *)&qe_xcd<S, FAM>;
-    const size_t lds = std::max((size_t)(2 * QE_MAX_EDGES + 16) * sizeof(float), d->e_lds);
+    const size_t lds = std::max((size_t)(2 * QE_MAX_EDGES + 16 + QE_CPB) * sizeof(float), d->e_lds);
     if (d->persist_blocks == 0) {
         int per_cu = 0, cus = 0;
         if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

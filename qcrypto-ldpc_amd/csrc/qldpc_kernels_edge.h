@@ -52,10 +52,14 @@ __device__ __forceinline__ bool qe_converged(const int *__restrict__ unsat, int 
 
 /* ------------------------------------------------------------------ check nodes -------------- */
 
-/* one chunk of QE_CPB checks of frame f; s_idx / s_val: QE_MAX_EDGES words of LDS each, s_unsat: one LDS int.  Every thread of the
- * workgroup must call it (it synchronises the workgroup). */
+/* one chunk of QE_CPB checks of frame f; s_idx / s_val: QE_MAX_EDGES words of LDS each, s_unsat: one LDS int, s_ptr: QE_CPB + 1 LDS ints.
+ * Every thread of the workgroup must call it (it synchronises the workgroup).
+ * The pass is latency-bound (a chunk is a chain of dependent round trips to the L2 / Infinity Cache, not bytes), so the chain is kept
+ * short: the chunk's slice of cn_ptr is staged into LDS with the edges (round 2 re-read it from global memory inside the fold loop:
+ * two dependent loads per round), and a thread asks for the indices of BOTH its edges before it waits and then for both gathers --
+ * two round trips for up to 2 * QE_THREADS edges where the one-edge-per-trip loop made four (profiles/r03_edge_engine_breakdown.txt). */
 template <int S, int FAM, bool COH = false>
-__device__ __forceinline__ void qe_cn_chunk(int f, int chunk, int *s_idx, float *s_val, int *s_unsat_p,
+__device__ __forceinline__ void qe_cn_chunk(int f, int chunk, int *s_idx, float *s_val, int *s_unsat_p, int *s_ptr,
                                             const float *__restrict__ v2c, float *__restrict__ c2v,
                                             const int *__restrict__ cn_ptr, const int *__restrict__ cn_tr,
                                             const int *__restrict__ cn_var, const uint32_t *__restrict__ sgn,
@@ -71,14 +75,19 @@ __device__ __forceinline__ void qe_cn_chunk(int f, int chunk, int *s_idx, float 
     float *cout = c2v + (size_t)f * E;
     const uint32_t *sw = sgn + (size_t)f * W;
     if (tid == 0) s_unsat = 0;
-    /* phase A: stage the chunk's edges (index + message + sign bit of the VN's last posterior) */
-    for (int e = tid; e < nE; e += QE_THREADS) {
-        const int slot = cn_tr[e0 + e];
-        const int v = cn_var[e0 + e];
-        const uint32_t bit = (qe_ldu<COH>(sw + (v >> 5)) >> (31 - (v & 31))) & 1u;
-        s_idx[e] = slot | (int)(bit << 31);
-        s_val[e] = syndrome_only ? 0.0f : qe_ld<COH>(vin + slot);
+    /* phase A: stage the chunk's edges (index + message + sign bit of the VN's last posterior) and its slice of cn_ptr */
+    const int pv = cn_ptr[c0 + (tid <= c1 - c0 ? tid : 0)];      /* asked for with the first indices, written to LDS behind them */
+    for (int base = 0; base < nE; base += 2 * QE_THREADS) {
+        const int ea = base + tid, eb = ea + QE_THREADS;
+        const bool a = ea < nE, b = eb < nE;
+        const int ia = e0 + (a ? ea : 0), ib = e0 + (b ? eb : 0);      /* clamped: every load below has a valid address, no branch in between */
+        const int sa = cn_tr[ia], va = cn_var[ia], sb = cn_tr[ib], vb = cn_var[ib];
+        const uint32_t wa = qe_ldu<COH>(sw + (va >> 5)), wb = qe_ldu<COH>(sw + (vb >> 5));
+        const float xa = syndrome_only ? 0.0f : qe_ld<COH>(vin + sa), xb = syndrome_only ? 0.0f : qe_ld<COH>(vin + sb);
+        if (a) { s_idx[ea] = sa | (int)(((wa >> (31 - (va & 31))) & 1u) << 31); s_val[ea] = xa; }
+        if (b) { s_idx[eb] = sb | (int)(((wb >> (31 - (vb & 31))) & 1u) << 31); s_val[eb] = xb; }
     }
+    if (tid <= c1 - c0) s_ptr[tid] = pv - e0;
     __syncthreads();
     /* phase B: one S-lane segment per check, butterfly all-reduce with wavefront shuffles */
     constexpr int PER_ROUND = QE_THREADS / S;
@@ -86,8 +95,8 @@ __device__ __forceinline__ void qe_cn_chunk(int f, int chunk, int *s_idx, float 
     uint32_t any_unsat = 0;
     for (int c = c0 + seg; c < c0 + QE_CPB; c += PER_ROUND) {
         const bool live = c < c1;
-        const int off = live ? cn_ptr[c] - e0 : 0;
-        const int deg = live ? cn_ptr[c + 1] - cn_ptr[c] : 0;
+        const int off = live ? s_ptr[c - c0] : 0;
+        const int deg = live ? s_ptr[c - c0 + 1] - off : 0;
         const bool act = s < deg;
         const float x = act ? s_val[off + s] : 0.0f;
         uint32_t par = act ? ((uint32_t)s_idx[off + s] >> 31) : 0u;
@@ -150,9 +159,10 @@ __global__ __launch_bounds__(QE_THREADS) void qe_cn(const float *__restrict__ v2
     __shared__ int s_idx[QE_MAX_EDGES];
     __shared__ float s_val[QE_MAX_EDGES];
     __shared__ int s_unsat;
+    __shared__ int s_ptr[QE_CPB + 1];
     const int f = blockIdx.y;
     if (!syndrome_only && done_at[f] >= 0) return;      /* the final success-flag pass covers every frame */
-    qe_cn_chunk<S, FAM>(f, blockIdx.x, s_idx, s_val, &s_unsat, v2c, c2v, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, syndrome_only, synd, Wm);
+    qe_cn_chunk<S, FAM>(f, blockIdx.x, s_idx, s_val, &s_unsat, s_ptr, v2c, c2v, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, syndrome_only, synd, Wm);
 }
 
 /* ------------------------------------------------------------------ variable nodes ----------- */
@@ -176,17 +186,21 @@ __device__ __forceinline__ void qe_vn_chunk(int f, int chunk, float *s_msg, cons
     const int sl0 = vn_ptr[v0], nS = vn_ptr[v1] - sl0;
     const float *cin = (sel ? c2v1 : c2v0) + (size_t)f * E + sl0;
     float *vout = v2c + (size_t)f * E + sl0;
+    /* the lane's own VN: its slot range and channel LLR are asked for before the chunk's messages are staged, so that the three loads
+     * travel with the staging loads instead of forming two more dependent round trips behind the barrier */
+    const int v = v0 + tid, vc = v < v1 ? v : v0;
+    const int pb = vn_ptr[vc], pe = vn_ptr[vc + 1];
+    const float y = llr[(size_t)f * N + vc];
     if (MODE != QK_VN_FIRST) {
         for (int k = tid; k < nS; k += QE_THREADS) s_msg[k] = qe_ld<COH>(cin + k);
         __syncthreads();
     }
-    const int v = v0 + tid;
     float tmp = 0.0f;
     if (v < v1) {
-        const int b = vn_ptr[v] - sl0, deg = vn_ptr[v + 1] - vn_ptr[v];
+        const int b = pb - sl0, deg = pe - pb;
         float sum = 0.0f;
         if (MODE != QK_VN_FIRST) for (int k = 0; k < deg; k++) sum += s_msg[b + k];
-        tmp = llr[(size_t)f * N + v] + sum;
+        tmp = y + sum;
         if (MODE == QK_VN_FIRST) { const float o = tmp - 0.0f; for (int k = 0; k < deg; k++) s_msg[b + k] = o; }
         else if (MODE == QK_VN_NORMAL) for (int k = 0; k < deg; k++) s_msg[b + k] = tmp - s_msg[b + k];
         if (MODE == QK_VN_POST && post_out) post_out[(size_t)f * N + v] = tmp;
@@ -297,12 +311,13 @@ __global__ __launch_bounds__(QE_THREADS) void qe_xcd(float *__restrict__ v2c, fl
                                                      int *__restrict__ unsat, int unsat_stride, int *__restrict__ done_at, qk_rule rule,
                                                      const uint32_t *__restrict__ synd, int Wm, int *__restrict__ ctl)
 {
-    extern __shared__ __align__(16) float s_dyn[];      /* max(2 * QE_MAX_EDGES + 16 words, QE_THREADS * max_dv floats) */
+    extern __shared__ __align__(16) float s_dyn[];      /* max(2 * QE_MAX_EDGES + 16 + QE_CPB words, QE_THREADS * max_dv floats) */
     __shared__ int s_role[2];                           /* block index, rank within the block's workgroups (-1: leave) */
     __shared__ int s_done;
     int *s_idx = reinterpret_cast<int *>(s_dyn);
     float *s_val = s_dyn + QE_MAX_EDGES;
     int *s_unsat = reinterpret_cast<int *>(s_dyn + 2 * QE_MAX_EDGES);
+    int *s_ptr = s_unsat + 8;                           /* QE_CPB + 1 ints */
     int *fault = ctl + QE_CTL_FAULT;
     if (threadIdx.x == 0) {
         unsigned xcc;
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(QE_THREADS) void qe_xcd(float *__restrict__ v2c, fl
     int ite = 0;
     for (; ite < n_ite; ite++) {
         for (int it = me; it < nCN; it += nb) {
-            qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, v2c, (ite & 1) ? c2v1 : c2v0, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, 0, synd, Wm);
+            qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, s_ptr, v2c, (ite & 1) ? c2v1 : c2v0, cn_ptr, cn_tr, cn_var, sgn, M, E, W, unsat, unsat_stride, ite, rule, 0, synd, Wm);
             __syncthreads();
         }
         qe_xcd_barrier(bar, ++round * nb, fault);
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(QE_THREADS) void qe_xcd(float *__restrict__ v2c, fl
     }
     /* success flag: syndrome of the final hard decisions into the last slot; iteration count */
     for (int it = me; it < nCN; it += nb) {
-        qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, v2c, c2v0, cn_ptr, cn_tr, cn_var, hard, M, E, W, unsat, unsat_stride, n_ite + 1, rule, 1, synd, Wm);
+        qe_cn_chunk<S, FAM, true>(f, it, s_idx, s_val, s_unsat, s_ptr, v2c, c2v0, cn_ptr, cn_tr, cn_var, hard, M, E, W, unsat, unsat_stride, n_ite + 1, rule, 1, synd, Wm);
         __syncthreads();
     }
     if (me == 0 && threadIdx.x == 0) {
