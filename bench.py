@@ -413,14 +413,14 @@ def main():
 
     # ---- BASELINE config 3: multi-rate H set {0.5, 0.7, 0.8, 0.9} chosen per epoch from the estimated QBER, a stream of epochs through
     #      the reconciliation sessions (what the ecd2 handlers call), HOST buffers in and out ----------------------------------------
-    def config3(peg_depth=2, rate_gap=None):
-        epochs_n, key_bits, batch = 512, 52429, 256      # the daemon's batched ingest (-L b<n>)
+    def config3(peg_depth=2, rate_gap=None, gap_profile=0):
+        epochs_n, key_bits, batch = 512, 52429, 512      # every rate group of the stream is one batch of its decoder
         rng = np.random.default_rng(42)
         qbers = rng.uniform(0.005, 0.06, epochs_n).astype(np.float32)
         alice = rng.integers(0, 2, (epochs_n, key_bits)).astype(np.uint8)
         bob = alice ^ (rng.random((epochs_n, key_bits)) < qbers[:, None])
         aw, bw = q.pack_bits(alice), q.pack_bits(bob)
-        kw = dict(device=local_rank, max_blocks=batch, peg_depth=peg_depth, rate_gap=rate_gap)
+        kw = dict(device=local_rank, max_blocks=batch, peg_depth=peg_depth, rate_gap=rate_gap, gap_profile=gap_profile)
         ra, rb = q.Recon(**kw), q.Recon(**kw)
         keys = [aw[i] for i in range(epochs_n)]
         ra.encode_blocks(keys, [key_bits] * epochs_n, qbers)                  # builds the codes of the table (warm-up)
@@ -480,7 +480,7 @@ def main():
                                   achieved=hot_bytes / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9,
                                   frac=hot_bytes / max(1e-9, sum(s_["total_ms"] for s_ in hot) * 1e-3) / 1e9 / HBM_PEAK_GBS),
                     workload="%d epochs x %d bits, QBER ~ U[0.5 %%, 6 %%] (seed 42), rate per epoch from {0.5, 0.7, 0.8, 0.9} (f = 1.4), mother code K = 57344 (%s) shortened + punctured per epoch, "
-                             "flooding SPA, one decode_blocks call for the stream" % (epochs_n, key_bits, "PEG depth %d" % peg_depth if peg_depth else "seeded shuffle"))
+                             "flooding SPA, one decode_blocks call for the stream, gap profile %d" % (epochs_n, key_bits, "PEG depth %d" % peg_depth if peg_depth else "seeded shuffle", gap_profile))
 
     cfg3 = cfg5 = ferd = None
     if rank == 0 and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32" and (N, K) == (65536, 52429):
@@ -492,9 +492,12 @@ def main():
                 cfg5["at_%d_frames" % f5] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"]}
                                              for k_ in ("fixed", "early_exit")}
         if not args.no_config3:
-            cfg3 = config3()      # the sessions' default: PEG-built mother codes (depth 2)
-            shuf = config3(peg_depth=0, rate_gap=0.035)      # round 2's codes and gap: the seeded socket shuffle, for comparison
-            cfg3["seeded_shuffle_mothers"] = {k_: shuf[k_] for k_ in ("value", "fer", "fer_after_second_round", "leaked_fraction", "ms_total", "avg_iterations", "wall_frac", "workload")}
+            cfg3 = config3()      # the sessions' default: PEG-built mother codes (depth 2), gaps as calibrated for them (leak 0.29 of the key)
+            keep = ("value", "fer", "fer_after_second_round", "leaked_fraction", "ms_total", "avg_iterations", "wall_frac", "epochs_per_rate", "workload")
+            fast = config3(gap_profile=1)      # the same codes planned with round 2's gaps: fewer iterations, leak 0.305
+            cfg3["peg_mothers_round2_gaps"] = {k_: fast[k_] for k_ in keep}
+            shuf = config3(peg_depth=0)        # round 2's codes and gaps: the seeded socket shuffle, for comparison
+            cfg3["seeded_shuffle_mothers"] = {k_: shuf[k_] for k_ in keep}
         if not args.no_fer_deep:
             ferd = fer_deep()
 

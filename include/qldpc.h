@@ -333,7 +333,11 @@ typedef struct qldpc_recon_cfg {
     int peg_depth;         /* 0: the information part of every code is the seeded socket shuffle (qldpc_code_ira); 1..4: grown by
                               progressive edge growth to that depth (qldpc_code_ira_peg; 2 = no 4-cycles), SURVEY.md 8f #3.  Both
                               sides must use the same value: the codes are derived from (size, rate, peg_depth, seed)          */
-    int reserved[1];       /* must be zero */
+    int gap_profile;       /* how far below capacity the plan stays, as a multiple c(R, K) of rate_gap (65536 / K)^0.4 per mother rate R:
+                              0 = as calibrated for the construction in use (PEG: 0.10 for R <= 0.75 on mothers of K >= 32 768, more on
+                              shorter ones, 0.85 for R <= 0.85, 1 above -- leak 0.29 of the key on the config-3 stream; seeded shuffle:
+                              0.6 / 0.9 / 1.0); 1 = round 2's 0.6 / 0.9 / 1.0 whatever the construction (fewer iterations, leak 0.305).
+                              Both sides must use the same value                                                            */
 } qldpc_recon_cfg;
 
 /* Travels in the parity packet (all fields uint32, little-endian like every ecd2 header). */

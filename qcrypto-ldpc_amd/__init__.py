@@ -519,7 +519,7 @@ class ReconCfg(C.Structure):
     _fields_ = [("device", C.c_int), ("efficiency", C.c_float), ("n_rates", C.c_int), ("rates", C.c_float * 8),
                 ("n_ite", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("key_quantum", C.c_int),
                 ("max_blocks", C.c_int), ("seed", C.c_uint64), ("schedule", C.c_int), ("mother_step", C.c_int), ("mother_max", C.c_int),
-                ("rate_gap", C.c_float), ("puncture", C.c_int), ("preload", C.c_int), ("peg_depth", C.c_int), ("reserved", C.c_int * 1)]
+                ("rate_gap", C.c_float), ("puncture", C.c_int), ("preload", C.c_int), ("peg_depth", C.c_int), ("gap_profile", C.c_int)]
 
 
 class ReconMsg(C.Structure):
@@ -574,7 +574,7 @@ class Recon:
 
     def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=None, rule=None, rule_param=None,
                  key_quantum=1024, max_blocks=1, seed=7, schedule="flooding", mother_step=None, mother_max=None, rate_gap=None,
-                 puncture=True, preload=False, peg_depth=None):
+                 puncture=True, preload=False, peg_depth=None, gap_profile=0):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
         cfg.device, cfg.efficiency, cfg.n_rates = int(device), float(efficiency), len(rates)
@@ -593,6 +593,7 @@ class Recon:
         if rate_gap is not None:
             cfg.rate_gap = float(rate_gap)
         cfg.puncture, cfg.preload = (1 if puncture else 2), int(bool(preload))
+        cfg.gap_profile = int(gap_profile)
         if peg_depth is not None:      # library default: 2 (mother codes by progressive edge growth)
             cfg.peg_depth = int(peg_depth)
         h = _vp()

@@ -262,6 +262,7 @@ extern "C" void qldpc_recon_cfg_default(qldpc_recon_cfg *c)
     c->rate_gap = 0.0f;             /* 0 = by rule: 0.03 for SPA, 0.05 for the min-sum family */
     c->puncture = 1;
     c->preload = 0;
+    c->gap_profile = 0;
     c->peg_depth = 2;               /* mother codes by progressive edge growth, no 4-cycles */
 }
 
@@ -389,7 +390,7 @@ extern "C" int qldpc_recon_create(const qldpc_recon_cfg *cfg, qldpc_recon **out)
     if (!cfg) return QLDPC_EINVAL;
     if (cfg->n_rates < 1 || cfg->n_rates > 8 || cfg->key_quantum < 32 || (cfg->key_quantum & 31) || cfg->max_blocks < 1 || cfg->n_ite < 1 ||
         !(cfg->efficiency > 0.0f) || cfg->mother_step < 0 || (cfg->mother_step & 31) || (cfg->mother_step > 0 && cfg->mother_max < cfg->mother_step) ||
-        !(cfg->rate_gap >= 0.0f && cfg->rate_gap < 0.5f) || cfg->peg_depth < 0 || cfg->peg_depth > 4 || cfg->reserved[0]) {
+        !(cfg->rate_gap >= 0.0f && cfg->rate_gap < 0.5f) || cfg->peg_depth < 0 || cfg->peg_depth > 4 || cfg->gap_profile < 0 || cfg->gap_profile > 1) {
         qldpc_set_error("recon_create: bad configuration");
         return QLDPC_EINVAL;
     }
@@ -533,7 +534,7 @@ static double gap_scale(const qldpc_recon_cfg &cfg, double R, int K)
     const int k = R <= 0.75 ? 0 : (R <= 0.85 ? 1 : 2);
     if (env[0] >= 0.0 && env[k] >= 0.0) return env[k];
     static const double peg[3] = {0.10, 0.85, 1.0}, shuffle[3] = {0.60, 0.90, 1.0};
-    if (cfg.peg_depth <= 0) return shuffle[k];
+    if (cfg.peg_depth <= 0 || cfg.gap_profile == 1) return shuffle[k];
     /* short low-rate mothers need more room: 0.1 from K = 32 768 upwards, 0.25 at 16 384, 0.6 at 8 192 (7 000-bit blocks: 24 failures of
      * 1 203 at rate 0.7 with 0.1 - 0.3, 1 with 0.6; 15 000-bit blocks: 1 - 2 of 1 100 at any value) */
     if (k == 0) return std::min(0.6, std::max(0.10, 0.10 * pow(32768.0 / (double)K, 1.3)));

@@ -8,7 +8,8 @@
  *   through a BSC of that QBER; reconciled = status OK and Bob's words == Alice's.
  *
  * usage: qldpc_stream [-e epochs] [-k key_bits] [-b max_blocks] [-S seed] [-r reps] [-q qmin:qmax] [-l (layered)] [-P depth (PEG mothers)]
- *                     [-g rate_gap] [-p (per-kernel profile of Bob's decoders in a second pass)]
+ *                     [-g rate_gap] [-G gap_profile] [-p (per-kernel profile of Bob's decoders in a second pass)]
+ *                     (defaults: 512 epochs x 52 429 bits, max_blocks 512, PEG depth 2 = the library's default)
  * prints one JSON object on stdout.
  */
 #include <math.h>
@@ -55,10 +56,10 @@ static void *part_main(void *arg)
 
 int main(int argc, char **argv)
 {
-    int epochs = 512, key_bits = 52429, batch = 256, reps = 3, layered = 0, profile = 0, peg = 0, opt, a_lanes = 0, b_lanes = 0, verbose = 0, split = 1;
+    int epochs = 512, key_bits = 52429, batch = 512, reps = 3, layered = 0, profile = 0, peg = 2, opt, a_lanes = 0, b_lanes = 0, verbose = 0, split = 1, gap_profile = 0;
     uint64_t seed = 42;
     double qmin = 0.005, qmax = 0.06, gap = 0.0;
-    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lpP:g:A:B:vT:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lpP:g:A:B:vT:G:")) != -1) {
         switch (opt) {
         case 'e': epochs = atoi(optarg); break;
         case 'k': key_bits = atoi(optarg); break;
@@ -73,6 +74,7 @@ int main(int argc, char **argv)
         case 'A': a_lanes = atoi(optarg); break;      /* lanes of Alice's / Bob's calls (QLDPC_RECON_LANES, set per call): diagnostics */
         case 'B': b_lanes = atoi(optarg); break;
         case 'v': verbose = 1; break;
+        case 'G': gap_profile = atoi(optarg); break;      /* qldpc_recon_cfg.gap_profile */
         case 'T': split = atoi(optarg); break;      /* experiment: T sessions on T host threads, each decoding every T-th epoch */
         default: fprintf(stderr, "usage: see the head of qldpc_stream.c\n"); return 2;
         }
@@ -98,6 +100,7 @@ int main(int argc, char **argv)
     cfg.schedule = layered ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING;
     cfg.rate_gap = (float)gap;
     cfg.peg_depth = peg;
+    cfg.gap_profile = gap_profile;
     qldpc_recon *ra = NULL, *rb = NULL;
     int rc;
     if ((rc = qldpc_recon_create(&cfg, &ra)) || (rc = qldpc_recon_create(&cfg, &rb))) return die("recon_create", rc);
