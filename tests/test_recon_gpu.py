@@ -245,3 +245,55 @@ def test_second_round_sends_the_withheld_parity_bits(q):
         bad = q.ReconMsg.from_buffer_copy(msg)
         bad.code_m += 32
         r.encode_planned(a, key_bits, bad, 0)
+
+
+def test_device_verification_crc_and_flip_count_match_the_host(q):
+    """Round 3: the CRC-32 of Alice's key (msg.crc32) and Bob's verification (CRC of the decoded bits, corrected-bit count) are computed on
+    the device by a chunked fold (rk_crc / rk_verify); they must be the byte-wise CRC (zlib over the masked words, most significant byte
+    first) and the true number of flipped bits, for lengths that end inside a word, on a word and on a mother-code boundary."""
+    import zlib
+    rng = np.random.default_rng(77)
+    r = q.Recon(max_blocks=8)
+    lens = [257, 1000, 8191, 8192, 30001, 52429, 57344, 65535]
+    keys, bobs, errs = [], [], []
+    for n in lens:
+        a, b, e = block(q, rng, n, 0.02)
+        keys.append(a), bobs.append(b), errs.append(e)
+    msgs, pars = r.encode_blocks(keys, lens, np.full(len(lens), 0.02, np.float32))
+    for n, a, m in zip(lens, keys, msgs):
+        w = a.copy()
+        if n & 31:
+            w[-1] &= np.uint32((0xFFFFFFFF << (32 - (n & 31))) & 0xFFFFFFFF)
+        assert m.crc32 == zlib.crc32(w.astype(">u4").tobytes()) == q.crc32_words(a, n), n
+    st, fixed, corrected, it = r.decode_blocks(bobs, lens, np.full(len(lens), 0.02, np.float32), msgs, pars)
+    assert (st == 0).all() and list(corrected) == errs
+    for a, f, n in zip(keys, fixed, lens):
+        assert (q.unpack_bits(f, n) == q.unpack_bits(a, n)).all()
+    bad = [q.ReconMsg.from_buffer_copy(m) for m in msgs]
+    bad[3].crc32 ^= 0x80000000      # one wrong CRC: that block alone is refused, its key stays Bob's, no flips are reported
+    st, fixed, corrected, it = r.decode_blocks(bobs, lens, np.full(len(lens), 0.02, np.float32), bad, pars)
+    assert list(st) == [0, 0, 0, -9, 0, 0, 0, 0] and corrected[3] == 0 and (fixed[3] == bobs[3]).all()
+
+
+def test_lanes_give_the_same_answers_as_one_rate_group_after_another(q, monkeypatch):
+    """Round 3: a call's rate groups decode side by side (lanes: host worker + compute stream + copy stream each).  The results must be
+    those of the serial order -- status, corrected keys, flip counts, iteration counts -- call after call (the first pipelined version
+    lost the tail blocks of a batch to a stream-ordered allocation that raced between lanes)."""
+    rng = np.random.default_rng(123)
+    n, key_bits = 96, 20011
+    qb = rng.uniform(0.006, 0.058, n).astype(np.float32)
+    alice = rng.integers(0, 2, (n, key_bits)).astype(np.uint8)
+    bob = alice ^ (rng.random((n, key_bits)) < qb[:, None])
+    aw, bw = q.pack_bits(alice), q.pack_bits(bob)
+    results = []
+    for lanes in ("1", "4", "4", "2"):
+        monkeypatch.setenv("QLDPC_RECON_LANES", lanes)
+        ra, rb = q.Recon(max_blocks=24), q.Recon(max_blocks=24)      # several batches per rate group: the double-buffered path
+        msgs, pars = ra.encode_blocks([aw[i] for i in range(n)], [key_bits] * n, qb)
+        st, fixed, co, it = rb.decode_blocks([bw[i] for i in range(n)], [key_bits] * n, qb, msgs, pars)
+        results.append(([(m.rate_index, m.crc32, m.n_punct) for m in msgs], [p.tobytes() for p in pars], st.tolist(), [f.tobytes() for f in fixed], co.tolist(), it.tolist()))
+    assert len({m[0] for m in results[0][0]}) >= 3                    # at least three rate groups in the call
+    for other in results[1:]:
+        assert other == results[0]
+    st = np.array(results[0][2])
+    assert (st == 0).mean() > 0.95 and all(results[0][3][i] == aw[i].tobytes() for i in np.nonzero(st == 0)[0])
