@@ -723,7 +723,10 @@ static int run_layered(qldpc_decoder *d)
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
     const size_t cell = d->msg_i8 ? 1 : sizeof(float);
     HIPCHK(hipMemcpyAsync(d->d_a, d->msg_i8 ? (const void *)d->d_llr8 : (const void *)d->d_llr, G * d->N * FG * cell, hipMemcpyDeviceToDevice, d->stream));   /* var_nodes = Y_N */
-    HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));                                                                                       /* messages = 0   */
+    /* messages = 0: fp32 sweeps that never mask a store (freeze = 0) do not clear and re-read E rows per frame group for that -- sweep 0's
+     * layer kernels take the messages as zero and write every row (config 5: 0.92 GB not written and not read per decode) */
+    const bool skip_clear = !d->msg_i8 && !d->freeze;
+    if (!skip_clear) HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));
     auto ballots = [&]() {
         if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr, d->N, d->d_done);
         else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)std::max(1, std::min((d->N + 32 * QK_WAVES - 1) / (32 * QK_WAVES), 8192 / std::max(1, d->G))), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
@@ -732,6 +735,7 @@ static int run_layered(qldpc_decoder *d)
     for (; ite < n_ite; ite++) {
         {
             prof_scope ps(d, KS_LAYER, bytes_layer(d));
+            d->layer_first = (skip_clear && ite == 0) ? 1 : 0;
             for (int l = 0; l < d->n_layers; l++)
                 for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
         }

@@ -60,6 +60,7 @@ struct qldpc_decoder {
     std::vector<bucket> cn_buckets, vn_buckets;
     std::vector<std::vector<bucket>> layer_buckets;   /* per layer */
     int n_layers;
+    int layer_first;                 /* layered fp32 run, sweep 0, messages not frozen: the layer kernels treat the messages as zero instead of reading a cleared array */
     /* state */
     float *d_llr, *d_a, *d_b;        /* flooding: a = v2c, b = c2v ; layered: a = post, b = msg */
     float *d_post;                   /* lazily allocated by fetch_post */

@@ -692,7 +692,8 @@ template <int V, int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ post, float *__restrict__ msg,
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
-                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M)
+                                                          int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M,
+                                                          int first /* sweep 0: messages are all zero -- they are not read (and the host has not cleared the array) */)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
@@ -725,7 +726,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
         for (int k = 0; k < DCMAX; k++)
             if (k < deg) {
                 qk_load<V>(x[k], pg + (size_t)vn[k] * FG);
-                qk_ldm<V>(m[k], mg + (size_t)(b + k) * FG);        /* the check's own messages: read once, written once per sweep */
+                if (!first) qk_ldm<V>(m[k], mg + (size_t)(b + k) * FG);        /* the check's own messages: read once, written once per sweep */
+                else {
+#pragma unroll
+                    for (int j = 0; j < V; j++) m[k][j] = 0.0f;
+                }
             }
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)
@@ -749,7 +754,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
         for (int k = 0; k < deg; k++) {
             float p[V], m[V];
             qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
-            qk_load<V>(m, mg + (size_t)(b + k) * FG);
+            if (!first) qk_load<V>(m, mg + (size_t)(b + k) * FG);
+            else {
+#pragma unroll
+                for (int j = 0; j < V; j++) m[j] = 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < V; j++) qk_acc_in<FAM>(acc[j], qk_prep<FAM>(p[j] - m[j]), rule);
         }
@@ -758,7 +767,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
         for (int k = 0; k < deg; k++) {
             float p[V], m[V], o[V];
             qk_load<V>(p, pg + (size_t)cn_var[b + k] * FG);
-            qk_load<V>(m, mg + (size_t)(b + k) * FG);
+            if (!first) qk_load<V>(m, mg + (size_t)(b + k) * FG);
+            else {
+#pragma unroll
+                for (int j = 0; j < V; j++) m[j] = 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < V; j++) { const float x = p[j] - m[j]; o[j] = acc[j].out(qk_prep<FAM>(x), rule); p[j] = x + o[j]; }
             qk_store_masked<V>(mg + (size_t)(b + k) * FG, o, frozen, any_frozen);

@@ -98,7 +98,7 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
         return;
     }
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M);
+                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first);
 }
 template <int V, int FAM>
 static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
