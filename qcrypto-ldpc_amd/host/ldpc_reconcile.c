@@ -34,7 +34,7 @@ static int g_opt_select = -1, g_opt_gpu_pa = -1, g_opt_fallback = -1, g_opt_max_
  * INTEGRATION.md section 2 describes does not parse these letters and has none of the code below them */
 static int g_opt_fault = -1, g_opt_dup = 0, g_opt_badhdr = 0, g_opt_noplan = 0, g_opt_badfrag = 0;
 #endif
-static int g_batch = -1, g_wait_ms = -1;
+static int g_batch = -1, g_wait_ms = -1, g_gap_profile = -1;
 
 static int ldpc_envInt(const char *name, int dflt)
 {
@@ -63,6 +63,7 @@ int ldpc_parseOption(const char *optarg)
         case 'n': g_opt_noplan = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* the initiator's plan comes back "no code for this QBER" */
         case 'z': g_opt_badfrag = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;    /* fragment 1 claims a word offset that is off by n */
 #endif
+        case 'G': g_gap_profile = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_gap_profile < 0 || g_gap_profile > 1) return 1; break;   /* qldpc_recon_cfg.gap_profile (both daemons alike) */
         case 'D': g_devices = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_devices < 1 || g_devices > LDPC_MAX_DEVICES) return 1; break;   /* blocks round-robin over n devices */
         case 'm': g_opt_margin = (int)strtol(p + 1, &end, 10); if (end == p + 1 || g_opt_margin < 0 || g_opt_margin > 100) return 1; break;   /* plan for qber + n/10 sigma of its estimate */
         case 'r': g_opt_second = (int)strtol(p + 1, &end, 10); if (end == p + 1) return 1; break;     /* r0: no second round, a failed decode goes straight to cascade */
@@ -124,6 +125,7 @@ int ldpc_init(int device)
         cfg.device = device + d;
         cfg.preload = 1;                   /* every mother code / encoder / decoder now: no construction, no device allocation per block */
         cfg.max_blocks = ldpc_batchSize();
+        if (g_gap_profile >= 0) cfg.gap_profile = g_gap_profile;
         if (qldpc_recon_create(&cfg, &g_recons[d]) != QLDPC_OK) {
             fprintf(stderr, "ldpc_init: device %d: %s\n", device + d, qldpc_last_error());
             ldpc_shutdown();

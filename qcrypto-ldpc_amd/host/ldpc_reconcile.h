@@ -91,7 +91,7 @@ extern const ALGORITHM_DATA_MNGR ALG_DATA_MNGR_LDPC;
 int ldpc_init(int device);
 /** the daemon's `-L` option (free in ecd2.c:26's getopt string): `-L 1` = choose LDPC after QBER estimation (qber_estim.c:301),
  *  `-L b<n>` batch size of the batched ingest, `-L w<ms>` its wait, `-L g` privacy amplification on the GPU, `-L f0` no cascade
- *  fallback, `-L r0` no second round (the withheld parity bits after a failed decode), `-L p<bytes>` largest parity packet, `-L D<n>` blocks round-robin over n devices (ldpc_deviceOf); several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
+ *  fallback, `-L r0` no second round (the withheld parity bits after a failed decode), `-L p<bytes>` largest parity packet, `-L D<n>` blocks round-robin over n devices (ldpc_deviceOf), `-L G<0|1>` qldpc_recon_cfg.gap_profile (0 = gaps calibrated for the mother codes, 1 = round 2's wider gaps; both daemons alike); several may be given comma separated: `-L 1,b8,g`.  Returns 0 or an error code. */
 int ldpc_parseOption(const char *optarg);
 int ldpc_selected(void);          /**< 1 after `-L 1` (or ECD2_LDPC=1 in the environment) */
 int ldpc_selectedFor(const ProcessBlock *pb);      /**< the per-block choice: selected AND the rate table covers the block's estimated QBER */
