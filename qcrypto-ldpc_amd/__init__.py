@@ -61,7 +61,7 @@ _vp = C.c_void_p
 class DecoderCfg(C.Structure):
     _fields_ = [("schedule", C.c_int), ("rule", C.c_int), ("rule_param", C.c_float), ("n_ite", C.c_int),
                 ("enable_syndrome", C.c_int), ("syndrome_depth", C.c_int), ("max_frames", C.c_int),
-                ("device", C.c_int), ("frames_per_lane", C.c_int), ("engine", C.c_int), ("freeze_messages", C.c_int), ("msg_dtype", C.c_int), ("quant_scale", C.c_float), ("compact", C.c_int), ("reserved", C.c_int * 2)]
+                ("device", C.c_int), ("frames_per_lane", C.c_int), ("engine", C.c_int), ("freeze_messages", C.c_int), ("msg_dtype", C.c_int), ("quant_scale", C.c_float), ("compact", C.c_int), ("layer_chain", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class KernelStat(C.Structure):
@@ -288,7 +288,7 @@ class Decoder:
 
     def __init__(self, code, K, n_ite, info_bits_pos=None, rule="SPA", rule_param=0.0, enable_syndrome=True,
                  syndrome_depth=1, n_frames=1, schedule="flooding", device=0, frames_per_lane=0, engine="auto",
-                 freeze_messages=False, msg_dtype="f32", quant_scale=0.0, compact="auto"):
+                 freeze_messages=False, msg_dtype="f32", quant_scale=0.0, compact="auto", layer_chain="auto"):
         cfg = DecoderCfg()
         _L.qldpc_decoder_cfg_default(C.byref(cfg))
         cfg.schedule = SCHEDULES[schedule]
@@ -305,6 +305,7 @@ class Decoder:
         cfg.msg_dtype = {"f32": 0, "f16": 1, "i8": 2}[msg_dtype]
         cfg.quant_scale = float(quant_scale)
         cfg.compact = {"auto": 0, "on": 1, "off": 2}[compact]
+        cfg.layer_chain = {"auto": 0, "on": 1, "off": 2}[layer_chain]
         pos = None
         if info_bits_pos is not None:
             pos = _np_i32(info_bits_pos)

@@ -18,6 +18,7 @@
 
 #include "qldpc_engine_int.h"
 #include "qldpc_kernels_edge.h"
+#include "qldpc_kernels_chain.h"
 #include "qldpc_kernels_compact.h"
 
 extern "C" int qldpc_device_count(void)
@@ -160,6 +161,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t); (void)hipFree(d->d_vn_tr);
+    (void)hipFree(d->d_chain_order); (void)hipFree(d->d_chain_dep); (void)hipFree(d->d_chain_ver); (void)hipFree(d->d_chain_ctl);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
@@ -308,6 +310,64 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
         d->layer_buckets.resize((size_t)code->n_layers);
         for (int l = 0; l < code->n_layers; l++)
             if ((rc = make_buckets(d, code->cn_ptr, code->layer_order + code->layer_ptr[l], code->layer_ptr[l + 1] - code->layer_ptr[l], CN_CAPS, 4, d->layer_buckets[(size_t)l]))) return rc;
+        /* A sweep as ONE launch in which a check waits for the earlier checks on its own VNs instead of for the whole layer before it
+         * (qldpc_kernels_chain.h).  fp32 messages, 64-frame groups, messages never frozen, check degree <= 40.  Measured on the N = 10^6 code
+         * (fixed 50 sweeps, fraction of the HBM peak, launch per layer -> one launch): 64 frames 0.575 -> 0.566, 128: 0.62 -> 0.68, 256: 0.63 -> 0.71,
+         * 512: 0.67 -> 0.70, 1 024: 0.69 -> 0.69 (early exit loses from 512 frames on: finished groups still draw tickets); config-2 batch (64
+         * groups, 437 checks per layer) 1 528 -> 1 300 Mbit/s; four session decoders side by side 19.0 -> 23.9 ms.  So: auto = 2 .. 8 groups and a
+         * layer launch of 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off. */
+        d->chain = 0;
+        {
+            const long per_layer = (long)d->M / std::max(1, code->n_layers) * d->G;
+            bool want = d->G >= 2 && d->G <= 8 && per_layer >= 8192 && per_layer < 65536 && code->n_layers > 1;
+            if (cfg->layer_chain == 1) want = true;
+            if (cfg->layer_chain == 2) want = false;
+            if (const char *e = getenv("QLDPC_LAYER_CHAIN")) want = atoi(e) != 0;
+            if (want && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && d->max_dc <= 40 && (long)d->M * d->G < (1L << 30) / 64) {
+                std::vector<int> depv((size_t)d->E), seen((size_t)d->N, 0), chain_order((size_t)d->M), lastpos((size_t)d->N, -1);
+                /* Execution order of the one-launch sweep: the code's layers in their order (so every VN sees its checks in the order of the
+                 * launch-per-layer sweep and of the oracle), but INSIDE a layer -- whose checks share no VN, so their order is free -- the checks
+                 * whose predecessors sit early in the order go first.  The waves in flight cover a window of a few thousand consecutive
+                 * tickets; with the layer in arbitrary order 4 in 10 checks found a predecessor from the tail of the layer before still in that
+                 * window and had to wait for it, sorted this way a check's predecessors are about one whole layer behind it. */
+                {
+                    std::vector<std::pair<int, int>> keyed;
+                    int at = 0;
+                    for (int l = 0; l < code->n_layers; l++) {
+                        keyed.clear();
+                        for (int i = code->layer_ptr[l]; i < code->layer_ptr[l + 1]; i++) {
+                            const int c = code->layer_order[i];
+                            int key = -1;
+                            for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) key = std::max(key, lastpos[(size_t)code->cn_var[k]]);
+                            keyed.emplace_back(key, c);
+                        }
+                        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first < y.first; });
+                        for (auto &kc : keyed) {
+                            const int c = kc.second;
+                            chain_order[(size_t)at] = c;
+                            for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) lastpos[(size_t)code->cn_var[k]] = at;
+                            at++;
+                        }
+                    }
+                }
+                /* rank of check c among the checks of VN v in execution order: walk the checks in that order, count per VN */
+                for (int p = 0; p < d->M; p++) {
+                    const int c = chain_order[(size_t)p];
+                    for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) {
+                        const int v = code->cn_var[k];
+                        const int dv = code->vn_ptr[v + 1] - code->vn_ptr[v];
+                        depv[(size_t)k] = (dv << 16) | seen[(size_t)v]++;
+                    }
+                }
+                if (code->max_dv < 32768) {
+                    if ((rc = dev_alloc(d, &d->d_chain_order, (size_t)d->M)) || (rc = dev_alloc(d, &d->d_chain_dep, (size_t)d->E)) ||
+                        (rc = dev_alloc(d, &d->d_chain_ver, (size_t)d->G * d->N)) || (rc = dev_alloc(d, &d->d_chain_ctl, QC_CTL_WORDS))) return rc;
+                    HIPCHK(hipMemcpy(d->d_chain_order, chain_order.data(), sizeof(int) * (size_t)d->M, hipMemcpyHostToDevice));
+                    HIPCHK(hipMemcpy(d->d_chain_dep, depv.data(), sizeof(int) * (size_t)d->E, hipMemcpyHostToDevice));
+                    d->chain = 1;
+                }
+            }
+        }
     }
     const size_t G = (size_t)d->G, FG = (size_t)d->FG;
     /* the fp32 LLR array [G][N][FG] is allocated on first use (ensure_llr): flooding decoders fed through qldpc_load_bits_* never read one */
@@ -376,7 +436,7 @@ extern "C" int qldpc_decoder_create(const qldpc_code *code, int K, const int *in
     if (cfg->enable_syndrome && cfg->syndrome_depth < 1) { qldpc_set_error("decoder_create: syndrome_depth=%d", cfg->syndrome_depth); return QLDPC_EINVAL; }
     if (cfg->frames_per_lane != 0 && cfg->frames_per_lane != 1 && cfg->frames_per_lane != 2 && cfg->frames_per_lane != 4) { qldpc_set_error("decoder_create: frames_per_lane=%d", cfg->frames_per_lane); return QLDPC_EINVAL; }
     if (cfg->msg_dtype < 0 || cfg->msg_dtype > 2) { qldpc_set_error("decoder_create: msg_dtype=%d", cfg->msg_dtype); return QLDPC_EINVAL; }
-    if (cfg->compact < 0 || cfg->compact > 2 || cfg->reserved[0] || cfg->reserved[1]) { qldpc_set_error("decoder_create: compact=%d (0 auto, 1 on, 2 off), reserved words must be zero", cfg->compact); return QLDPC_EINVAL; }
+    if (cfg->compact < 0 || cfg->compact > 2 || cfg->layer_chain < 0 || cfg->layer_chain > 2 || cfg->reserved[0]) { qldpc_set_error("decoder_create: compact=%d, layer_chain=%d (0 auto, 1 on, 2 off), reserved words must be zero", cfg->compact, cfg->layer_chain); return QLDPC_EINVAL; }
     if (!(cfg->quant_scale >= 0.0f) || cfg->quant_scale > 64.0f) { qldpc_set_error("decoder_create: quant_scale=%g", (double)cfg->quant_scale); return QLDPC_EINVAL; }
     qldpc_decoder *d = new (std::nothrow) qldpc_decoder();
     if (!d) return QLDPC_ENOMEM;
@@ -727,6 +787,18 @@ static int run_layered(qldpc_decoder *d)
      * layer kernels take the messages as zero and write every row (config 5: 0.92 GB not written and not read per decode) */
     const bool skip_clear = !d->msg_i8 && !d->freeze;
     if (!skip_clear) HIPCHK(hipMemsetAsync(d->d_b, 0, G * d->E * FG * cell, d->stream));
+    bool chain = false;
+    if constexpr (V == 1) {
+        chain = d->chain != 0;
+        if (chain) {
+            if (d->chain_blocks == 0) { d->chain_blocks = qldpc_chain_resident_blocks(d); if (d->chain_blocks < 64) chain = false, d->chain = 0;
+                if (getenv("QLDPC_DEBUG")) fprintf(stderr, "libqldpc: one-launch layered sweep: %d resident workgroups of %d waves\n", d->chain_blocks, QK_WAVES); }
+            if (chain) {
+                HIPCHK(hipMemsetAsync(d->d_chain_ver, 0, sizeof(int) * G * d->N, d->stream));
+                HIPCHK(hipMemsetAsync(d->d_chain_ctl, 0, sizeof(int) * QC_CTL_WORDS, d->stream));
+            }
+        }
+    }
     auto ballots = [&]() {
         if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr, d->N, d->d_done);
         else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)std::max(1, std::min((d->N + 32 * QK_WAVES - 1) / (32 * QK_WAVES), 8192 / std::max(1, d->G))), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
@@ -736,8 +808,14 @@ static int run_layered(qldpc_decoder *d)
         {
             prof_scope ps(d, KS_LAYER, bytes_layer(d));
             d->layer_first = (skip_clear && ite == 0) ? 1 : 0;
-            for (int l = 0; l < d->n_layers; l++)
-                for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
+            if (chain) {
+                HIPCHK(hipMemsetAsync(d->d_chain_ctl + QC_CTL_SHARD0, 0, sizeof(int) * 32 * QC_SHARDS, d->stream));      /* the ticket counters; the fault word stays */
+                qldpc_launch_layer_chain(d, ite);
+                LAUNCHCHK();
+            }
+            else
+                for (int l = 0; l < d->n_layers; l++)
+                    for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
             ballots();
@@ -754,6 +832,17 @@ static int run_layered(qldpc_decoder *d)
     d->last_iters = std::min(ite, n_ite);
     ballots();
     LAUNCHCHK();
+    if (chain) {
+        /* a wait that ran into its bound left the fault word set: the decode cannot be trusted; say so and go back to a launch per layer */
+        int ctl[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(ctl, d->d_chain_ctl, sizeof(ctl), hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (ctl[1]) {
+            d->chain = 0;
+            qldpc_set_error("layered decode: a dependency wait of the one-launch sweep timed out (decoder switched back to a launch per layer; run again)");
+            return QLDPC_EHIP;
+        }
+    }
     return QLDPC_OK;
 }
 

@@ -60,6 +60,8 @@ struct qldpc_decoder {
     std::vector<bucket> cn_buckets, vn_buckets;
     std::vector<std::vector<bucket>> layer_buckets;   /* per layer */
     int n_layers;
+    /* one launch per sweep for small batches (qldpc_kernels_chain.h): execution order, per-edge {dv, rank}, per-VN version counters, ticket / fault words */
+    int chain, chain_blocks; int *d_chain_order, *d_chain_dep, *d_chain_ver, *d_chain_ctl; int chain_sweeps;
     int layer_first;                 /* layered fp32 run, sweep 0, messages not frozen: the layer kernels treat the messages as zero instead of reading a cleared array */
     /* state */
     float *d_llr, *d_a, *d_b;        /* flooding: a = v2c, b = c2v ; layered: a = post, b = msg */
@@ -158,6 +160,8 @@ static inline int want_ballots(const qldpc_decoder *d, int mode)
 /* kernel-launch dispatchers (qldpc_launch.hip); `first`: the check pass of iteration 0 in coded-LLR mode */
 template <int V> void qldpc_launch_cn(qldpc_decoder *d, const bucket &b, bool first);
 template <int V> void qldpc_launch_layer(qldpc_decoder *d, const bucket &b);
+void qldpc_launch_layer_chain(qldpc_decoder *d, int sweep);      /* V = 1 only */
+int qldpc_chain_resident_blocks(qldpc_decoder *d);
 template <int V, int MODE> void qldpc_launch_vn(qldpc_decoder *d, const bucket &b, float *post_out);
 #define QLDPC_DECLARE_LAUNCH(V)                                                                   \
     extern template void qldpc_launch_cn<V>(qldpc_decoder *, const bucket &, bool);                \

@@ -171,3 +171,47 @@ template void qldpc_launch_layer<QL_V>(qldpc_decoder *, const bucket &);
 template void qldpc_launch_vn<QL_V, QK_VN_FIRST>(qldpc_decoder *, const bucket &, float *);
 template void qldpc_launch_vn<QL_V, QK_VN_NORMAL>(qldpc_decoder *, const bucket &, float *);
 template void qldpc_launch_vn<QL_V, QK_VN_POST>(qldpc_decoder *, const bucket &, float *);
+
+#if QL_V == 1
+#include "qldpc_kernels_chain.h"
+
+/* one sweep of the horizontal-layered schedule as ONE launch (qldpc_kernels_chain.h); compiled with the V = 1 instances only */
+template <int DCMAX, int FAM>
+static void launch_chain_one(qldpc_decoder *d, int sweep)
+{
+    qk_rule r{d->cfg.rule, d->cfg.rule_param};
+    const int total = d->M * d->G;
+    const unsigned grid = (unsigned)std::max(1, std::min((total + QK_WAVES - 1) / QK_WAVES, d->chain_blocks));
+    hipLaunchKernelGGL((qk_cn_layer_chain<DCMAX, FAM>), dim3(grid), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, d->d_chain_order, d->M, d->G, d->d_cn_ptr, d->d_cn_var,
+                       d->d_chain_dep, d->d_chain_ver, d->d_chain_ctl, sweep, d->N, (size_t)d->E * d->FG, d->d_done, r,
+                       d->has_synd ? d->d_synd : nullptr, d->layer_first);
+}
+template <int FAM>
+static void launch_chain_fam(qldpc_decoder *d, int sweep)
+{
+    if (d->max_dc <= 12) launch_chain_one<12, FAM>(d, sweep);
+    else if (d->max_dc <= 20) launch_chain_one<20, FAM>(d, sweep);
+    else launch_chain_one<40, FAM>(d, sweep);
+}
+void qldpc_launch_layer_chain(qldpc_decoder *d, int sweep)
+{
+    switch (family_of(d->cfg.rule)) {
+    case QK_FAM_MS: launch_chain_fam<QK_FAM_MS>(d, sweep); break;
+    case QK_FAM_SPA: launch_chain_fam<QK_FAM_SPA>(d, sweep); break;
+    case QK_FAM_LSPA: launch_chain_fam<QK_FAM_LSPA>(d, sweep); break;
+    default: launch_chain_fam<QK_FAM_AMS>(d, sweep); break;
+    }
+}
+/* resident workgroups the chip holds for the instance this decoder uses (the grid of the persistent launch) */
+int qldpc_chain_resident_blocks(qldpc_decoder *d)
+{
+    int per_cu = 0, cus = 0;
+    const void *fn = nullptr;
+    const int fam = family_of(d->cfg.rule);
+#define QC_PICK(F) (d->max_dc <= 12 ? (const void *)&qk_cn_layer_chain<12, F> : (d->max_dc <= 20 ? (const void *)&qk_cn_layer_chain<20, F> : (const void *)&qk_cn_layer_chain<40, F>))
+    fn = fam == QK_FAM_MS ? QC_PICK(QK_FAM_MS) : (fam == QK_FAM_SPA ? QC_PICK(QK_FAM_SPA) : (fam == QK_FAM_LSPA ? QC_PICK(QK_FAM_LSPA) : QC_PICK(QK_FAM_AMS)));
+#undef QC_PICK
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, QK_THREADS, 0) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+#endif

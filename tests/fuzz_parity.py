@@ -88,6 +88,7 @@ while time.time() - t0 < budget:
         if engine == "edges":
             V = 0
         freeze = bool(rng.integers(0, 2)) and dtype != "i8"
+        chain = str(rng.choice(["auto", "on", "on", "off"]))        # only acts on layered fp32 runs of the frames engine with 64-frame groups, messages not frozen
         compact = str(rng.choice(["auto", "on", "on", "off"]))      # only acts with early exit on the flooding schedule of the frames engine, messages not frozen
         x = rng.integers(0, 2, (F, code.N)).astype(np.uint8) if coset else np.zeros((F, code.N), np.uint8)
         s = np.stack([og.syndrome(xx)[1] for xx in x]) if coset else None
@@ -99,11 +100,11 @@ while time.time() - t0 < budget:
             g2, order = layer_graph(code, var, chk)
             tgt = s[:, order] if coset else None
         ref = O.decode(g2, llr, rule, param, n_ite, sched, synd, 1, n_threads=8, target=tgt, msg_fp16=(dtype == "f16"), msg_i8=(dtype == "i8"))
-        desc = "%s F=%d q=%.3f %s(%g) %s %s synd=%d coset=%d ite=%d V=%d eng=%s freeze=%d compact=%s" % (cname, F, qber, rule, param, sched, dtype, synd, coset, n_ite, V, engine, freeze, compact)
+        desc = "%s F=%d q=%.3f %s(%g) %s %s synd=%d coset=%d ite=%d V=%d eng=%s freeze=%d compact=%s chain=%s" % (cname, F, qber, rule, param, sched, dtype, synd, coset, n_ite, V, engine, freeze, compact, chain)
         dec = None
         try:
             dec = q.Decoder(code, code.N, n_ite, rule=rule, rule_param=param, n_frames=F, schedule=sched, enable_syndrome=synd, frames_per_lane=V,
-                            engine=engine, freeze_messages=freeze, msg_dtype=dtype, compact=compact)
+                            engine=engine, freeze_messages=freeze, msg_dtype=dtype, compact=compact, layer_chain=chain)
             dec.load_bits(torch.from_numpy(i32(q.pack_bits(y))).cuda(), torch.full((F,), float(mag), device="cuda"))
             if coset:
                 dec.load_syndrome(torch.from_numpy(i32(q.pack_bits(s))).cuda())

@@ -540,3 +540,25 @@ def test_spa_tolerance_at_scale(q, O, torch, peg, engine):
     assert abs((1.0 - g_good.mean()) - p) <= ci, (1.0 - g_good.mean(), p, ci)
     same = (hard == ref["hard"]).all(axis=1)
     assert same[o_good].mean() >= 0.999                                  # and on frames the oracle reconciles it is the same word
+
+
+@pytest.mark.parametrize("rule,param", EXACT[:3])
+@pytest.mark.parametrize("frames", [5, 64, 200])
+def test_one_launch_layered_sweep_is_bit_exact(q, O, torch, peg, rule, param, frames):
+    """Round 3 (qldpc_kernels_chain.h): a layered sweep as ONE launch -- a check waits for the earlier checks on its own VNs (per-VN
+    version counters, agent-coherent posterior rows) instead of for the whole layer before it.  The order of the updates on every VN is
+    that of the launch-per-layer sweep, so hard decisions, iteration counts and success flags must be those of the oracle given the
+    code's row order, and in fixed-iteration mode the posteriors bit for bit: one ragged group, one full group, several groups."""
+    code, og = peg
+    order, _, _ = code.layer_order()
+    var, chk = og.edges()
+    inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+    og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    llr = bsc_frames(np.random.default_rng(40 + frames), frames, 1008, 0.065 if rule in ("NMS", "OMS") else 0.045, 2.6)
+    for synd in (True, False):
+        ref = O.decode(og, llr, rule, param, 14, "hlayered", synd, 1, n_threads=8)
+        dec = q.Decoder(code, 1008, 14, rule=rule, rule_param=param, n_frames=frames, schedule="hlayered", enable_syndrome=synd, layer_chain="on")
+        hard, it, ok, post = staged(q, torch, dec, llr, want_post=not synd)
+        assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
+        if not synd:
+            assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()     # bit-exact floats
