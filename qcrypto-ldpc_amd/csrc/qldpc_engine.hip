@@ -837,6 +837,7 @@ static int run_layered(qldpc_decoder *d)
         int ctl[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(ctl, d->d_chain_ctl, sizeof(ctl), hipMemcpyDeviceToHost, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));
+        if (getenv("QLDPC_DEBUG")) fprintf(stderr, "libqldpc: one-launch layered sweeps: %d sweeps x %d checks x %d groups, %d checks waited for a predecessor, %d polls on top\n", d->last_iters, d->M, d->G, ctl[2], ctl[3]);
         if (ctl[1]) {
             d->chain = 0;
             qldpc_set_error("layered decode: a dependency wait of the one-launch sweep timed out (decoder switched back to a launch per layer; run again)");

@@ -32,6 +32,8 @@
 #include "qldpc_kernels.h"
 
 #define QC_CTL_FAULT 1
+#define QC_CTL_WAITS 2                /* checks whose first poll did not pass / polls they made on top (diagnostics) */
+#define QC_CTL_SPINS 3
 #define QC_SHARDS 64                  /* ticket counters: shard j hands out tickets j, j + 64, j + 128, ...; each on a 128-byte line of its own */
 #define QC_CTL_SHARD0 32
 #define QC_CTL_WORDS (QC_CTL_SHARD0 + 32 * QC_SHARDS)
@@ -56,7 +58,11 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_chain(float *__restric
      * counters, issued in front of the loads of its own message rows, which depend on nothing} and {its posterior rows}.  The stores of a
      * check are not waited for on their own: its counters are raised (QC_DEFER) once the NEXT check's rows have arrived -- s_waitcnt vmcnt(0)
      * there covers the stores too -- unless the next check's poll does not pass at once, in which case the pending counts go out first (the
-     * next check may be waiting for this very wave). */
+     * next check may be waiting for this very wave).  Measured alternatives on the N = 10^6 code, one 64-frame group (fraction of the HBM peak):
+     * this form 0.566; counts raised right after a drain of the check's own stores 0.47; raised once the next check's poll has returned
+     * (stores drained there) 0.32; once poll AND message rows have returned 0.26 -- the acknowledgement of write-through stores is slow, and
+     * anything that waits for it in line costs more than the late publication does (which makes half the checks of a one-group sweep
+     * wait for a predecessor: 625 000 of 1.2 million, QLDPC_DEBUG counters; 2 % with four groups per check). */
     auto draw = [&]() -> int {
         int t = 0;
         if (lane == 0) t = shard + QC_SHARDS * __hip_atomic_fetch_add(my_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -102,9 +108,10 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_chain(float *__restric
                     pend_ctr = nullptr;
                 }
                 unsigned spins = 0;
+                if (lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_WAITS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* diagnostics (QLDPC_DEBUG): checks that had to wait */
                 for (;;) {
                     if (!ok) ok = __hip_atomic_load(vg + my_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-                    if (__all(ok)) break;
+                    if (__all(ok)) { if (lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_SPINS, (int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > QC_SPIN_LIMIT) {
                         if (lane == 0) __hip_atomic_store(ctl + QC_CTL_FAULT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
