@@ -93,3 +93,19 @@ def test_encoder_construction_option():
     assert len(r) == 1 and r[0]["fra"] == 100 and r[0]["fe"] < 60      # N = 136: short code, FER band of README_LDPC.md:937-974 without puncturing is far below
     p = subprocess.run([SIM, "-a", alist, "-G", "CHOLESKY"], capture_output=True, text=True, timeout=60)
     assert p.returncode != 0
+
+
+def test_config3_stream_timed_from_c():
+    """host/qldpc_stream.c: BASELINE config 3 with nothing but the C ABI in the timed region -- Alice's encode_blocks, ONE decode_blocks call for
+    the whole stream on Bob's side (lanes, device-side verification).  A small stream here: every epoch reconciled, Bob's words equal Alice's
+    (the tool compares them itself), leak in the band of the plan, all four table rates in use."""
+    import json
+    exe = os.path.join(ROOT, "qcrypto-ldpc_amd", "host", "qldpc_stream")
+    if not os.path.exists(exe):
+        pytest.skip("qldpc_stream not built")
+    p = subprocess.run([exe, "-e", "96", "-k", "20011", "-b", "64", "-r", "2", "-S", "5", "-p"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["reconciled"] == d["epochs"] == 96 and sum(d["epochs_per_rate"]) == 96 and sum(1 for x in d["epochs_per_rate"] if x) >= 3
+    assert 0.25 < d["leaked_fraction"] < 0.36 and d["failed_per_rate"] == [0, 0, 0, 0]
+    assert d["ms_best"] > 0 and d["kernels"]["cn_update"]["launches"] > 0
