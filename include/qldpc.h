@@ -331,7 +331,7 @@ typedef struct qldpc_recon_cfg {
                               is shortened to its length per frame), so a handful of codes serve every block; 0 = a code per size */
     int mother_max;        /* 65536 */
     float rate_gap;        /* the effective rate stays rate_gap (65536 / K)^0.4 below the BSC capacity 1 - h(q); 0 = by rule
-                              (0.035 SPA / LSPA, 0.05 min-sum family): measured FER 0 over QBER 0.3 .. 8 %, DESIGN.md     */
+                              (0.035 SPA / LSPA, 0.05 min-sum family), times a factor per mother rate and size: gap_profile below */
     int puncture;          /* 1 (default): puncture parity VNs down to the target efficiency; 0 / 2: disclose all M    */
     int preload;           /* 1: build every (mother size, rate) entry in qldpc_recon_create -- no code construction and no
                               device allocation afterwards for blocks of up to mother_max bits                          */
