@@ -190,9 +190,10 @@ typedef struct qldpc_decoder_cfg {
                             a group can be saved, 2 = never                                                          */
     int layer_chain;     /* horizontal layered, fp32 messages, 64-frame groups, freeze_messages = 0, check degree <= 40: run a sweep as ONE launch in
                             which a check waits for the earlier checks on its own variable nodes (per-VN version counters, agent-coherent posterior
-                            rows) instead of one launch per layer of mutually VN-disjoint checks.  Same results bit for bit.  0 = auto (2 to 8 frame
-                            groups and a layer launch of 8 192 .. 65 535 waves: measured +10 .. 13 % on the N = 10^6 code with 128 - 256 frames, no gain
-                            with one group, a loss with many groups or several decoders running side by side), 1 = on, 2 = off          */
+                            rows) instead of one launch per layer of mutually VN-disjoint checks.  Same results bit for bit.  0 = auto (fixed-iteration
+                            runs with 2 to 8 frame groups and a layer launch of 8 192 .. 65 535 waves: measured +10 .. 13 % on the N = 10^6 code with 128 - 256
+                            frames; no gain with one group or with the per-sweep early exit, a loss with many groups or several decoders side by side),
+                            1 = on, 2 = off          */
     int reserved[1];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 

@@ -314,12 +314,13 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
          * (qldpc_kernels_chain.h).  fp32 messages, 64-frame groups, messages never frozen, check degree <= 40.  Measured on the N = 10^6 code
          * (fixed 50 sweeps, fraction of the HBM peak, launch per layer -> one launch): 64 frames 0.575 -> 0.566, 128: 0.62 -> 0.68, 256: 0.63 -> 0.71,
          * 512: 0.67 -> 0.70, 1 024: 0.69 -> 0.69 (early exit loses from 512 frames on: finished groups still draw tickets); config-2 batch (64
-         * groups, 437 checks per layer) 1 528 -> 1 300 Mbit/s; four session decoders side by side 19.0 -> 23.9 ms.  So: auto = 2 .. 8 groups and a
-         * layer launch of 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off. */
+         * groups, 437 checks per layer) 1 528 -> 1 300 Mbit/s; four session decoders side by side 19.0 -> 23.9 ms; with the per-sweep early exit the gain
+         * at 128 - 256 frames is inside the run-to-run spread (+2 % .. -9 %).  So: auto = fixed-iteration runs with 2 .. 8 groups and a layer launch of
+         * 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off. */
         d->chain = 0;
         {
             const long per_layer = (long)d->M / std::max(1, code->n_layers) * d->G;
-            bool want = d->G >= 2 && d->G <= 8 && per_layer >= 8192 && per_layer < 65536 && code->n_layers > 1;
+            bool want = !cfg->enable_syndrome && d->G >= 2 && d->G <= 8 && per_layer >= 8192 && per_layer < 65536 && code->n_layers > 1;
             if (cfg->layer_chain == 1) want = true;
             if (cfg->layer_chain == 2) want = false;
             if (const char *e = getenv("QLDPC_LAYER_CHAIN")) want = atoi(e) != 0;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_chain(float *__restric
                                                         const int *__restrict__ cn_ptr, const int *__restrict__ cn_var, const int *__restrict__ dep,
                                                         int *__restrict__ ver, int *__restrict__ ctl, int sweep,
                                                         int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule,
-                                                        const u64 *__restrict__ synd, int first)
+                                                        const u64 *__restrict__ synd, int first, int diag)
 {
     const int lane = threadIdx.x & 63;      /* every wavefront of the workgroup works for itself: no workgroup-wide step anywhere below */
     const int total = M * G;
@@ -108,10 +108,10 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_chain(float *__restric
                     pend_ctr = nullptr;
                 }
                 unsigned spins = 0;
-                if (lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_WAITS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* diagnostics (QLDPC_DEBUG): checks that had to wait */
+                if (diag && lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_WAITS, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* diagnostics (QLDPC_DEBUG only: one address, it serialises): checks that had to wait */
                 for (;;) {
                     if (!ok) ok = __hip_atomic_load(vg + my_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
-                    if (__all(ok)) { if (lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_SPINS, (int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (__all(ok)) { if (diag && lane == 0) __hip_atomic_fetch_add(ctl + QC_CTL_SPINS, (int)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > QC_SPIN_LIMIT) {
                         if (lane == 0) __hip_atomic_store(ctl + QC_CTL_FAULT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

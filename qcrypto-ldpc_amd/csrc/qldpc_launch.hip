@@ -184,7 +184,7 @@ static void launch_chain_one(qldpc_decoder *d, int sweep)
     const unsigned grid = (unsigned)std::max(1, std::min((total + QK_WAVES - 1) / QK_WAVES, d->chain_blocks));
     hipLaunchKernelGGL((qk_cn_layer_chain<DCMAX, FAM>), dim3(grid), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, d->d_chain_order, d->M, d->G, d->d_cn_ptr, d->d_cn_var,
                        d->d_chain_dep, d->d_chain_ver, d->d_chain_ctl, sweep, d->N, (size_t)d->E * d->FG, d->d_done, r,
-                       d->has_synd ? d->d_synd : nullptr, d->layer_first);
+                       d->has_synd ? d->d_synd : nullptr, d->layer_first, getenv("QLDPC_DEBUG") ? 1 : 0);
 }
 template <int FAM>
 static void launch_chain_fam(qldpc_decoder *d, int sweep)
