@@ -316,7 +316,18 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
          * 512: 0.67 -> 0.70, 1 024: 0.69 -> 0.69 (early exit loses from 512 frames on: finished groups still draw tickets); config-2 batch (64
          * groups, 437 checks per layer) 1 528 -> 1 300 Mbit/s; four session decoders side by side 19.0 -> 23.9 ms; with the per-sweep early exit the gain
          * at 128 - 256 frames is inside the run-to-run spread (+2 % .. -9 %).  So: auto = fixed-iteration runs with 2 .. 8 groups and a layer launch of
-         * 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off. */
+         * 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off.  (Fewer or more waves in flight per SIMD,
+         * QLDPC_CHAIN_WAVES: no difference outside the box-to-box spread, tools/gpu/r3_g47.sh.)  It works on explicit messages: the min-sum rules,
+         * which run on the compressed check state below, do not use it. */
+        /* Min-sum sweeps on a compressed check state (qldpc_kernels_cst.h): bit-identical, 0.59 x the bytes on the N = 10^6 code.  fp32 messages,
+         * 64-frame groups, messages never frozen, check degree <= 32, and the state must fit the message array.  QLDPC_LAYER_CST = 0 keeps the dc messages. */
+        d->layer_cst = 0;
+        const char *chain_env = getenv("QLDPC_LAYER_CHAIN");
+        const bool chain_asked = chain_env ? atoi(chain_env) != 0 : cfg->layer_chain == 1;      /* an explicit request for the one-launch sweep keeps the explicit messages it works on */
+        if (!chain_asked && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && family_of(cfg->rule) == QK_FAM_MS && d->max_dc <= 32 &&
+            (size_t)d->M * 1024 <= (size_t)d->E * 256)
+            d->layer_cst = 1;
+        if (const char *e = getenv("QLDPC_LAYER_CST")) d->layer_cst = d->layer_cst && atoi(e) != 0;
         d->chain = 0;
         {
             const long per_layer = (long)d->M / std::max(1, code->n_layers) * d->G;
@@ -324,7 +335,7 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
             if (cfg->layer_chain == 1) want = true;
             if (cfg->layer_chain == 2) want = false;
             if (const char *e = getenv("QLDPC_LAYER_CHAIN")) want = atoi(e) != 0;
-            if (want && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && d->max_dc <= 40 && (long)d->M * d->G < (1L << 30) / 64) {
+            if (want && !d->layer_cst && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && d->max_dc <= 40 && (long)d->M * d->G < (1L << 30) / 64) {
                 std::vector<int> depv((size_t)d->E), seen((size_t)d->N, 0), chain_order((size_t)d->M), lastpos((size_t)d->N, -1);
                 /* Execution order of the one-launch sweep: the code's layers in their order (so every VN sees its checks in the order of the
                  * launch-per-layer sweep and of the oracle), but INSIDE a layer -- whose checks share no VN, so their order is free -- the checks
@@ -597,6 +608,12 @@ static double moved_vn(const qldpc_decoder *d, int mode)
     return (msgs + d->N / 8.0) * live_frames(d) + d->N;
 }
 static double bytes_layer(const qldpc_decoder *d) { return 4.0 * d->E * msg_b(d) * live_frames(d); }
+/* what a sweep moves: with the compressed check state 2 E posterior rows + 8 M state rows per 64-frame group */
+static double moved_layer(const qldpc_decoder *d)
+{
+    if (!d->layer_cst) return bytes_layer(d);
+    return (2.0 * d->E * 4.0 + 8.0 * d->M * 4.0) * live_frames(d);
+}
 
 template <int V, int MODE>
 static int vn_pass(qldpc_decoder *d, float *post_out)
@@ -807,7 +824,7 @@ static int run_layered(qldpc_decoder *d)
     int ite = 0;
     for (; ite < n_ite; ite++) {
         {
-            prof_scope ps(d, KS_LAYER, bytes_layer(d));
+            prof_scope ps(d, KS_LAYER, bytes_layer(d), moved_layer(d));
             d->layer_first = (skip_clear && ite == 0) ? 1 : 0;
             if (chain) {
                 HIPCHK(hipMemsetAsync(d->d_chain_ctl + QC_CTL_SHARD0, 0, sizeof(int) * 32 * QC_SHARDS, d->stream));      /* the ticket counters; the fault word stays */

@@ -1,0 +1,96 @@
+/*
+ * qldpc_kernels_cst.h -- horizontal-layered min-sum sweeps on a COMPRESSED check state (fp32, 64-frame groups).
+ *
+ * In the layered schedule (Decoder_LDPC_BP_horizontal_layered::_decode_single_ite; ML/BPSK_nrldpc_sim.m:29-69 is the same
+ * recursion) a check's dc messages are private to that check: written at the end of its update, read back at the start of its
+ * next one, by nobody else.  For the min-sum family (MS / OMS / NMS: tools::Update_rule_{MS,OMS,NMS}) those dc floats per frame
+ * take only two magnitudes,
+ *     messages[k] = +-( |contribution_k| == min1 ? cst1 : cst2 ),
+ * so the check keeps, per frame, {cst1, cst2} and two dc-bit masks -- bit k of `took1`: edge k took cst1; bit k of `neg`: the
+ * message of edge k is negative -- i.e. FOUR 256-byte rows per check and 64-frame group instead of dc, and rebuilds the very
+ * float it would have read: same magnitude bits, same sign bit (a -0.0 stays a -0.0).  contribution = var_nodes - message, the
+ * fold and var_nodes = contribution + message are untouched, so the sweep is bit-identical to the one that stores every message
+ * (and to the oracle); on a tie min2 == min1 both forms give cst1.
+ *
+ * HBM bytes of a sweep per 64-frame group: 2 E rows (posteriors read + written) + 8 M rows (state read + written) against 4 E
+ * rows with explicit messages: 0.61 x on the N = 10^6 code of BASELINE configs[4] (dc = 18).  Unlike the flooding form of this
+ * idea (the VN pass has to GATHER the state rows of its checks, which is fabric-bound), nothing but the
+ * owner ever touches a check's state here: its four rows are one contiguous kilobyte.
+ * (Masks per FRAME rather than ballots per EDGE: a lane needs bit `lane` of dc wave-uniform words for the ballot form, i.e. a
+ * 64 x dc bit transpose through v_readlane / v_writelane on the way in and out; the per-frame masks need none and cost 224 bytes
+ * more per check.)
+ *
+ * The state lives in the message array the decoder owns anyway ([G][E][64] floats per group): rows of check c at c * 256
+ * floats -- {cst1, cst2, neg, took1}[64]; M * 1024 <= E * 256 bytes is checked by the host, check degree <= 32.
+ * Sweep 0 takes the state as zero (messages +0.0) without reading it, as qk_cn_layer does.  freeze_messages = 0 only.
+ */
+#ifndef QLDPC_KERNELS_CST_H
+#define QLDPC_KERNELS_CST_H
+
+#include "qldpc_kernels.h"
+
+#define QK_CST_ROWS 4      /* {cst1, cst2, neg, took1} */
+
+/* the message of edge k for this lane's frame, rebuilt from the check's state */
+__device__ __forceinline__ float qk_cst_msg(uint32_t neg, uint32_t took1, int k, float c1, float c2)
+{
+    return qk_withsign(((took1 >> k) & 1u) ? c1 : c2, (neg >> k) << 31);
+}
+
+template <int DCMAX>
+__global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict__ post, float *__restrict__ st,
+                                                              const int *__restrict__ list, int n_list,
+                                                              const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
+                                                              int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, const u64 *__restrict__ synd, int M,
+                                                              int first)
+{
+    static_assert(DCMAX > 0 && DCMAX <= 32, "one mask bit per edge");
+    const int g = blockIdx.y;
+    if (qk_group_done<1>(done, g)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * QK_WAVES + wave;
+    if (i >= n_list) return;
+    float *pg = post + (size_t)g * N * 64 + lane;
+
+    const int c = list[i];
+    const int b = cn_ptr[c];
+    const int deg = cn_ptr[c + 1] - b;
+    float *crow = st + (size_t)g * group_stride + (size_t)c * (64 * QK_CST_ROWS) + lane;
+
+    int vn[DCMAX];
+#pragma unroll
+    for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+    float x[DCMAX];
+#pragma unroll
+    for (int k = 0; k < DCMAX; k++)
+        if (k < deg) x[k] = pg[(size_t)vn[k] * 64];
+    float c1 = 0.0f, c2 = 0.0f;
+    uint32_t neg = 0u, took1 = 0u;
+    if (!first) {
+        c1 = qk_ldm1(crow); c2 = qk_ldm1(crow + 64);
+        neg = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crow + 128)); took1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crow + 192));
+    }
+    qk_acc<QK_FAM_MS> acc;
+    acc.begin();
+    if (synd) acc.sign = (uint32_t)((synd[(size_t)g * M + c] >> lane) & 1ull) << 31;
+#pragma unroll
+    for (int k = 0; k < DCMAX; k++)
+        if (k < deg) { x[k] = x[k] - qk_cst_msg(neg, took1, k, c1, c2); acc.in(x[k]); }
+    acc.finish(rule);
+    neg = 0u; took1 = 0u;
+#pragma unroll
+    for (int k = 0; k < DCMAX; k++)
+        if (k < deg) {
+            const float o = acc.out(x[k], rule);
+            pg[(size_t)vn[k] * 64] = x[k] + o;      /* posteriors are re-read by later layers: cached */
+            neg |= (qk_bits(o) >> 31) << k;
+            took1 |= (fabsf(x[k]) == acc.min1 ? 1u : 0u) << k;
+        }
+    __builtin_nontemporal_store(acc.cst1, crow);
+    __builtin_nontemporal_store(acc.cst2, crow + 64);
+    __builtin_nontemporal_store(neg, reinterpret_cast<uint32_t *>(crow + 128));
+    __builtin_nontemporal_store(took1, reinterpret_cast<uint32_t *>(crow + 192));
+}
+
+#endif /* QLDPC_KERNELS_CST_H */

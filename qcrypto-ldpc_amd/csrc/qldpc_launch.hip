@@ -5,6 +5,7 @@
  */
 #include "qldpc_engine_int.h"
 #include "qldpc_kernels_h16.h"
+#include "qldpc_kernels_cst.h"
 
 #ifndef QL_V
 #error "compile with -DQL_V=1, 2 or 4"
@@ -97,6 +98,12 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
                                d->N, (size_t)d->E * 64, d->d_done, qi_rule_of(d), d->has_synd ? d->d_synd : nullptr, d->M);
         return;
     }
+    if (d->layer_cst) {      /* min-sum on the compressed check state (qldpc_kernels_cst.h): the host set this only for V = 1, degrees <= 32 */
+        if constexpr (V == 1 && FAM == QK_FAM_MS && CAP > 0)
+            hipLaunchKernelGGL((qk_cn_layer_cst<(CAP > 32 ? 32 : CAP)>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
+                               d->N, (size_t)d->E * d->FG, d->d_done, r, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first);
+        return;
+    }
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
                        d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first);
 }
@@ -182,7 +189,7 @@ static void launch_chain_one(qldpc_decoder *d, int sweep)
     qk_rule r{d->cfg.rule, d->cfg.rule_param};
     const int total = d->M * d->G;
     const unsigned grid = (unsigned)std::max(1, std::min((total + QK_WAVES - 1) / QK_WAVES, d->chain_blocks));
-    hipLaunchKernelGGL((qk_cn_layer_chain<DCMAX, FAM>), dim3(grid), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, d->d_chain_order, d->M, d->G, d->d_cn_ptr, d->d_cn_var,
+    hipLaunchKernelGGL((qk_cn_layer_chain<DCMAX, FAM>), dim3(grid), dim3(QK_THREADS), (size_t)d->chain_lds, d->stream, d->d_a, d->d_b, d->d_chain_order, d->M, d->G, d->d_cn_ptr, d->d_cn_var,
                        d->d_chain_dep, d->d_chain_ver, d->d_chain_ctl, sweep, d->N, (size_t)d->E * d->FG, d->d_done, r,
                        d->has_synd ? d->d_synd : nullptr, d->layer_first, getenv("QLDPC_DEBUG") ? 1 : 0);
 }
@@ -202,16 +209,24 @@ void qldpc_launch_layer_chain(qldpc_decoder *d, int sweep)
     default: launch_chain_fam<QK_FAM_AMS>(d, sweep); break;
     }
 }
-/* resident workgroups the chip holds for the instance this decoder uses (the grid of the persistent launch) */
+/* resident workgroups the chip holds for the instance this decoder uses (the grid of the persistent launch).  QLDPC_CHAIN_WAVES = n caps it at n
+ * workgroups per CU (n waves per SIMD), QLDPC_CHAIN_LDS = bytes additionally makes every workgroup ask for that much LDS it never touches, so that the
+ * dispatcher cannot stack more on a CU.  Measured on the N = 10^6 code (tools/gpu/r3_g46.sh, r3_g47.sh): 3 / 4 / 5 waves per SIMD by the grid alone
+ * 0.58 / 0.58 / 0.56 of the HBM peak at 64 frames, 1 377 / 1 482 / 1 470 Mbit/s at 128, 1 418 / 1 557 / 1 548 at 256 -- differences at 64 frames are inside
+ * the box-to-box spread, so the default stays what the occupancy query gives. */
 int qldpc_chain_resident_blocks(qldpc_decoder *d)
 {
     int per_cu = 0, cus = 0;
+    int n = 8;
+    if (const char *e = getenv("QLDPC_CHAIN_WAVES")) n = std::max(1, std::min(8, atoi(e)));
+    d->chain_lds = 0;
+    if (const char *e = getenv("QLDPC_CHAIN_LDS")) d->chain_lds = std::max(0, std::min(65536, atoi(e)));
     const void *fn = nullptr;
     const int fam = family_of(d->cfg.rule);
 #define QC_PICK(F) (d->max_dc <= 12 ? (const void *)&qk_cn_layer_chain<12, F> : (d->max_dc <= 20 ? (const void *)&qk_cn_layer_chain<20, F> : (const void *)&qk_cn_layer_chain<40, F>))
     fn = fam == QK_FAM_MS ? QC_PICK(QK_FAM_MS) : (fam == QK_FAM_SPA ? QC_PICK(QK_FAM_SPA) : (fam == QK_FAM_LSPA ? QC_PICK(QK_FAM_LSPA) : QC_PICK(QK_FAM_AMS)));
 #undef QC_PICK
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, QK_THREADS, 0) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) return 0;
-    return per_cu * cus;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, QK_THREADS, (size_t)d->chain_lds) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess) return 0;
+    return std::min(per_cu, n) * cus;
 }
 #endif

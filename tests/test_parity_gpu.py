@@ -562,3 +562,33 @@ def test_one_launch_layered_sweep_is_bit_exact(q, O, torch, peg, rule, param, fr
         assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all()
         if not synd:
             assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()     # bit-exact floats
+
+
+@pytest.mark.parametrize("rule,param", EXACT[:3])
+@pytest.mark.parametrize("frames", [3, 64, 130])
+def test_layered_min_sum_on_the_compressed_check_state_is_bit_exact(q, O, torch, monkeypatch, rule, param, frames):
+    """Round 3 (qldpc_kernels_cst.h): layered MS / OMS / NMS sweeps keep {cst1, cst2} and two dc-bit masks per check and frame instead of the dc
+    messages and rebuild each message from them.  Same floats in, same floats out: hard decisions, iteration counts, success flags and (fixed
+    iterations) posteriors must be those of the oracle, with the state on (the default for these rules) and with explicit messages
+    (QLDPC_LAYER_CST = 0), on an irregular code whose checks fall into several degree buckets; and the syndrome (coset) form through load_bits."""
+    code = q.Code.ira(4096, 3277, 0.125, 11, 3, 7)
+    assert 8 < code.max_cn_degree <= 32
+    order, _, _ = code.layer_order()
+    var, chk = code.edges()
+    inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+    og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    llr = bsc_frames(np.random.default_rng(70 + frames), frames, code.N, 0.03, 2.9)
+    for synd in (True, False):
+        ref = O.decode(og, llr, rule, param, 12, "hlayered", synd, 1, n_threads=8)
+        got = {}
+        for cst in ("1", "0"):
+            monkeypatch.setenv("QLDPC_LAYER_CST", cst)
+            dec = q.Decoder(code, code.N, 12, rule=rule, rule_param=param, n_frames=frames, schedule="hlayered", enable_syndrome=synd, layer_chain="off")
+            dec.profile(True)
+            hard, it, ok, post = staged(q, torch, dec, llr, want_post=not synd)
+            assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all(), (cst, synd)
+            if not synd:
+                assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all(), cst     # bit-exact floats
+            lay = {k["name"]: k for k in dec.profile_read()}["layer_update"]
+            got[cst] = lay["moved_bytes"] / lay["alg_bytes"]
+        assert got["0"] == 1.0 and got["1"] < 0.75      # the state path really ran: 2 E + 8 M rows instead of 4 E
