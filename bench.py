@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-early", action="store_true", help="skip the early-exit leg")
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-message-storage variant leg")
+    ap.add_argument("--no-layered", action="store_true", help="skip the horizontal-layered leg on the headline code")
     ap.add_argument("--no-int8", action="store_true", help="skip the 8-bit fixed-point variant leg")
     ap.add_argument("--no-fer-deep", action="store_true", help="skip the deep frame-error-rate leg (>= 2^20 frames at the headline QBER + waterfall points)")
     ap.add_argument("--fer-frames", type=int, default=1 << 20, help="frames of the deep FER point at the headline QBER")
@@ -188,10 +189,10 @@ def main():
     if rank == 0:
         log("frames ready: %d per GPU (%.1f s), code N=%d K=%d M=%d E=%d" % (F, time.time() - t0, N, K, code.M, code.E))
 
-    def make_decoder(enable_syndrome, msg_dtype=None):
+    def make_decoder(enable_syndrome, msg_dtype=None, schedule=None):
         msg_dtype = msg_dtype or args.msg_dtype
         d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
-                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype, schedule=args.schedule)
+                      n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype, schedule=schedule or args.schedule)
         d.set_stream(torch.cuda.current_stream(device))
         return d
 
@@ -303,6 +304,33 @@ def main():
             del dec
             torch.cuda.empty_cache()
         return res
+
+    # ---- the same code, rule and iteration cap on AFF3CT's OTHER schedule: horizontal layered (Decoder_LDPC_BP_horizontal_layered; the harness keeps
+    # the case commented out, VAR/main.cpp (alist-v1.0.1):220-258).  Not the headline -- the reference runs flooding -- but the fastest bit-exact fp32
+    # operating point of this library: half the iterations, and min-sum sweeps run on the compressed check state (qldpc_kernels_cst.h).
+    def layered():
+        res = {}
+        for name, synd in (("fixed", False), ("early_exit", True)):
+            dec = make_decoder(synd, "f32", "hlayered")
+            dec.profile(True)
+            step(dec)
+            dec.profile_clear()
+            dtl = timed(dec, max(1, args.steps), 0)
+            lay = {s["name"]: s for s in dec.profile_read()}["layer_update"]
+            dec.profile(False)
+            gl, itl, nl = verdicts(dec)
+            res[name] = dict(value=gl * K * max(1, args.steps) / dtl / 1e6, unit="Mbit/s", fer=1.0 - gl / nl, avg_sweeps=itl / nl, sweeps_launched=dec.last_run_iterations,
+                             ms_per_step=dtl / max(1, args.steps) * 1e3, avg_sweep_ms=lay["total_ms"] / lay["launches"])
+            if not synd:      # with early exit finished groups leave the sweeps: the bytes of a launch are not those of the full batch, no fraction is quoted
+                res[name].update(roofline_frac=lay["alg_bytes"] / (lay["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 roofline_moved_frac=lay["moved_bytes"] / (lay["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            del dec
+            torch.cuda.empty_cache()
+        res["workload"] = "the headline code and batch, horizontal-layered %s(%.2f) over %d colour layers, <= %d sweeps" % (args.rule, args.alpha, code.n_layers, args.n_ite)
+        res["note"] = "roofline_frac prices 4 E rows per sweep (section 8(d)); min-sum sweeps move 2 E + 8 M rows (compressed check state): roofline_moved_frac"
+        return res
+
+    lay2 = layered() if (not args.no_layered and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32") else None
 
     fp16 = variant("f16") if not args.no_fp16 else None
     int8 = variant("i8") if (not args.no_int8 and args.rule in ("MS", "OMS", "NMS")) else None
@@ -497,7 +525,9 @@ def main():
             cfg5 = config5(f5s[0])              # batch 64 (one frame group: 6 667 waves per colour layer)
             for f5 in f5s[1:]:                  # the same code with enough frames to fill the chip
                 big = config5(f5)
-                cfg5["at_%d_frames" % f5] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} | {"roofline_frac": big[k_]["roofline"]["frac"], "roofline_moved_frac": big[k_]["roofline"]["moved_frac"]}
+                # (early exit with several groups: finished groups leave the sweeps, so a launch's bytes are not the full batch's -- no fraction quoted)
+                cfg5["at_%d_frames" % f5] = {k_: {kk: big[k_][kk] for kk in ("value", "unit", "fer", "avg_sweeps", "ms_per_step")} |
+                                             ({"roofline_frac": big[k_]["roofline"]["frac"], "roofline_moved_frac": big[k_]["roofline"]["moved_frac"]} if (k_ == "fixed" or f5 <= 64) else {})
                                              for k_ in ("fixed", "early_exit")}
         if not args.no_config3:
             cfg3 = config3()      # the sessions' default: PEG-built mother codes (depth 2), gaps as calibrated for them (leak 0.29 of the key)
@@ -604,6 +634,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "early_exit": early,
+            "layered_schedule": lay2,
             "fp16_messages": fp16,
             "int8_messages": int8,
             "fer_deep": ferd,

@@ -61,5 +61,9 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one()
     assert len(wf) == 8 and all(p_["frames"] == 65536 and p_["undetected_errors"] == 0 for p_ in wf)
     assert wf[0]["fer"] < 0.01 < wf[3]["fer"]              # NMS: clean at 2.5 %, inside the waterfall at 3.25 %
     assert wf[4]["fer"] < wf[0]["fer"] + 1e-3 and wf[7]["fer"] < wf[3]["fer"]      # SPA is the better rule at every point
-    fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["frac"], c5["early_exit"]["roofline"]["frac"]]
+    # round 3: min-sum layered sweeps run on the compressed check state -- fewer bytes moved than section 8(d) prices, same words
+    assert c5["fixed"]["roofline"]["moved_bytes_per_sweep"] < 0.7 * c5["fixed"]["roofline"]["alg_bytes_per_sweep"] and "compressed" in c5["fixed"]["roofline"]["kernel"]
+    ls = d["layered_schedule"]      # the headline code and batch on AFF3CT's other schedule
+    assert ls["fixed"]["fer"] == 0.0 and ls["early_exit"]["fer"] == 0.0 and ls["fixed"]["value"] > d["value"] and ls["early_exit"]["value"] > e["value"] and ls["early_exit"]["avg_sweeps"] < 8
+    fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["frac"], c5["early_exit"]["roofline"]["frac"], c5["fixed"]["roofline"]["moved_frac"], ls["fixed"]["roofline_moved_frac"]]
     assert all(0.0 < f <= 1.0 for f in fracs), fracs

@@ -4,8 +4,8 @@ export TMPDIR=/tmp
 export QLDPC_CODE_CACHE=/tmp/qcc; mkdir -p $QLDPC_CODE_CACHE
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_r03; mkdir -p $O
 B="python3 $GRAFT_REPO_ROOT/bench.py"
-FIXED="--steps 20 --warmup 1 --no-early --no-fp16 --no-int8 --no-config3 --no-config5 --no-cpu --no-fer-deep"
-C5="--steps 2 --warmup 1 --no-early --no-fp16 --no-int8 --no-config3 --no-cpu --no-fer-deep --config5-frames 64"
+FIXED="--steps 20 --warmup 1 --no-early --no-layered --no-fp16 --no-int8 --no-config3 --no-config5 --no-cpu --no-fer-deep"
+C5="--steps 2 --warmup 1 --no-early --no-layered --no-fp16 --no-int8 --no-config3 --no-cpu --no-fer-deep --config5-frames 64"
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/fixed50 -o fixed50 --output-format csv -- $B $FIXED > $O/fixed50.json 2> $O/fixed50.err; echo "fixed50 rc=$?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/fixed50_fetch -o f --output-format csv -- $B $FIXED > /dev/null 2> $O/fixed50_fetch.err; echo "fetch rc=$?"
