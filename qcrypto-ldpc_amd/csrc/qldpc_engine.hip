@@ -643,7 +643,7 @@ static int synd_pass(qldpc_decoder *d, const u64 *mask, int skip_done)
     for (int part = 0; part < (Mp < d->M ? 2 : 1); part++) {
         const int lo = part ? Mp : 0, hi = part ? d->M : Mp;
         const int bx = std::max(1, std::min((hi - lo + 255) / 256, 4096 / std::max(1, d->G)));
-        hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)(g8 * bx)), dim3(256), 0, d->stream, mask, d->d_cn_var_t, d->max_dc, d->M, d->N,
+        hipLaunchKernelGGL((qk_syndrome<V>), dim3((unsigned)((d->G < 8 ? d->G : g8) * bx)), dim3(256), 0, d->stream, mask, d->d_cn_var_t, d->max_dc, d->M, d->N,
                            d->d_unsat, d->d_done, skip_done, d->has_synd ? d->d_synd : nullptr, d->G, bx, lo, hi, part);
     }
     LAUNCHCHK();
@@ -836,8 +836,11 @@ static int run_layered(qldpc_decoder *d)
                     for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
-            ballots();
-            LAUNCHCHK();
+            {
+                prof_scope ps(d, KS_SYND, 0.0, (double)d->N * 4.0 * d->n_frames);      /* the sign ballots of the posteriors: N rows read */
+                ballots();
+                LAUNCHCHK();
+            }
             if ((rc = synd_pass<V>(d, d->d_sgn, 1))) return rc;
             if ((rc = status_pass<V>(d, ite + 1))) return rc;
             if (d->poll_every > 0 && ((ite + 1) % d->poll_every) == 0) {

@@ -168,6 +168,10 @@ __device__ __forceinline__ uint32_t qk_wlane(uint32_t old, uint32_t val, int lan
     asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(lane));
     return old;
 }
+__device__ __forceinline__ u64 qk_uniform64(u64 v)
+{
+    return ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 __device__ __forceinline__ float qk_ldm1(const float *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ float qk_ldm1(const __half *p) { return __half2float(__ushort_as_half(__builtin_nontemporal_load(reinterpret_cast<const unsigned short *>(p)))); }
 __device__ __forceinline__ void qk_put(float *p, float v) { *p = v; }
@@ -792,29 +796,40 @@ __global__ __launch_bounds__(QK_THREADS) void qk_post_ballots(const float *__res
     /* one wavefront takes 32 consecutive VNs per trip; their 32 sgn + 32 hard ballot words (of frame slot j) leave in ONE store
      * instruction -- lane 2k carries the sgn word of VN k, lane 2k + 1 its hard word (lane-0 stores were one instruction per word) */
     for (int v0 = (blockIdx.x * QK_WAVES + wave) * 32; v0 < N; v0 += gridDim.x * QK_WAVES * 32) {
-        u64 mine[V];
+        uint32_t mlo[V], mhi[V];
 #pragma unroll
-        for (int j = 0; j < V; j++) mine[j] = 0;
-        for (int k = 0; k < 32; k++) {
-            const int v = v0 + k;
-            if (v >= N) break;      /* wave-uniform */
-            float p[V];
-            qk_load<V>(p, post + ((size_t)g * N + v) * FG + lane * V);
+        for (int j = 0; j < V; j++) { mlo[j] = 0; mhi[j] = 0; }
+        /* eight rows asked for before the first is looked at (one row per trip left a wave with 256 bytes in flight: the 256 MB of
+         * config 5's posteriors took as long as a third of a sweep); the ballot words reach their lanes by v_writelane */
 #pragma unroll
-            for (int j = 0; j < V; j++) {
-                u64 s = __ballot((qk_bits(p[j]) >> 31) != 0);
-                u64 h = __ballot(!(p[j] >= 0.0f));
-                const size_t bi = ((size_t)g * N + v) * V + j;
-                const u64 dm = done[(size_t)g * V + j];      /* converged frames keep the ballots they converged with */
-                if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
-                if (lane == 2 * k) mine[j] = s;
-                if (lane == 2 * k + 1) mine[j] = h;
+        for (int k0 = 0; k0 < 32; k0 += 8) {
+            float p[8][V];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (v0 + k0 + t < N) qk_load<V>(p[t], post + ((size_t)g * N + v0 + k0 + t) * FG + lane * V);      /* wave-uniform */
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int v = v0 + k0 + t;
+                if (v >= N) break;      /* wave-uniform */
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    u64 s = __ballot((qk_bits(p[t][j]) >> 31) != 0);
+                    u64 h = __ballot(!(p[t][j] >= 0.0f));
+                    const size_t bi = ((size_t)g * N + v) * V + j;
+                    const u64 dm = done[(size_t)g * V + j];      /* converged frames keep the ballots they converged with */
+                    if (dm) {      /* (the old words come through a vector load of a wave-uniform address: readfirstlane keeps s and h in SGPRs for v_writelane) */
+                        const u64 os = sgn[bi], oh = hard[bi];
+                        s = (s & ~dm) | (qk_uniform64(os) & dm); h = (h & ~dm) | (qk_uniform64(oh) & dm);
+                    }
+                    mlo[j] = qk_wlane(mlo[j], (uint32_t)s, 2 * (k0 + t)); mhi[j] = qk_wlane(mhi[j], (uint32_t)(s >> 32), 2 * (k0 + t));
+                    mlo[j] = qk_wlane(mlo[j], (uint32_t)h, 2 * (k0 + t) + 1); mhi[j] = qk_wlane(mhi[j], (uint32_t)(h >> 32), 2 * (k0 + t) + 1);
+                }
             }
         }
         const int v = v0 + (lane >> 1);
         if (v < N) {
 #pragma unroll
-            for (int j = 0; j < V; j++) ((lane & 1) ? hard : sgn)[((size_t)g * N + v) * V + j] = mine[j];
+            for (int j = 0; j < V; j++) ((lane & 1) ? hard : sgn)[((size_t)g * N + v) * V + j] = ((u64)mhi[j] << 32) | mlo[j];
         }
     }
 }
@@ -835,8 +850,10 @@ __global__ __launch_bounds__(256) void qk_syndrome(const u64 *__restrict__ mask,
                                                    int c_lo, int c_hi, int gated)
 {
     const int id = blockIdx.x;
-    const int g = (id & 7) + 8 * ((id >> 3) / bx);
-    const int chunk = (id >> 3) % bx;
+    /* fewer than 8 groups: one XCD per group would leave the others idle (config 5's single group ran on 32 of 256 CUs: 94 us per pass);
+     * the host then launches G * bx workgroups and a group's chunks go round all XCDs -- its ballots are a few megabytes */
+    const int g = G < 8 ? id % G : (id & 7) + 8 * ((id >> 3) / bx);
+    const int chunk = G < 8 ? id / G : (id >> 3) % bx;
     if (g >= G) return;
     if (skip_done && qk_group_done<V>(done, g)) return;
     if (gated) {
