@@ -193,7 +193,10 @@ typedef struct qldpc_decoder_cfg {
                             rows) instead of one launch per layer of mutually VN-disjoint checks.  Same results bit for bit.  0 = auto (fixed-iteration
                             runs with 2 to 8 frame groups and a layer launch of 8 192 .. 65 535 waves: measured +10 .. 13 % on the N = 10^6 code with 128 - 256
                             frames; no gain with one group or with the per-sweep early exit, a loss with many groups or several decoders side by side),
-                            1 = on, 2 = off          */
+                            1 = on, 2 = off.  The one-launch sweep works on explicit messages.  Layered MS / OMS / NMS sweeps (fp32, 64-frame groups,
+                            check degree <= 32, freeze_messages = 0) otherwise keep a COMPRESSED CHECK STATE -- the two magnitudes a check's messages
+                            take and two dc-bit masks per frame instead of the dc messages (csrc/qldpc_kernels_cst.h): the same floats, 0.61 x the
+                            bytes on the N = 10^6 code -- so for those rules auto never picks the one-launch sweep, and 1 gives up the state for it */
     int reserved[1];     /* must be zero                                                         */
 } qldpc_decoder_cfg;
 
