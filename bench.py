@@ -341,8 +341,8 @@ def main():
     # 95 % Clopper-Pearson upper bound, mean / max iterations.  The reference publishes FE / FRA per QBER from 30 frames a point on
     # DVB-S2 rate 0.8 (BS/data_dvb/data3 (DVB S2)/DVB_S2_N_64800_K_51840_CR_0.8.txt:31-36: SPA 0 / 30 up to 3.0 %, 30 / 30 at 3.5 %;
     # NMS with factor 1: 30 / 30 at 1.5 %, :24-25) -- printed beside ours as context (another H: DVB-S2 tables are AFF3CT built-ins).
-    def fer_point(code_, enc_, rule, param, qber, n_frames, seed0, batch=4096):
-        dec_ = q.Decoder(code_, enc_.K, args.n_ite, rule=rule, rule_param=param, enable_syndrome=True, n_frames=batch, device=local_rank)
+    def fer_point(code_, enc_, rule, param, qber, n_frames, seed0, batch=4096, schedule="flooding"):
+        dec_ = q.Decoder(code_, enc_.K, args.n_ite, rule=rule, rule_param=param, enable_syndrome=True, n_frames=batch, device=local_rank, schedule=schedule)
         dec_.set_stream(torch.cuda.current_stream(device))
         mag_ = torch.full((batch,), q.bsc_llr(qber), dtype=torch.float32, device=device)
         out_ = torch.empty((batch, (code_.N + 31) // 32), dtype=torch.int32, device=device)
@@ -382,6 +382,9 @@ def main():
             for qb in (0.025, 0.0275, 0.03, 0.0325):
                 wf.append(fer_point(code, enc, rule, param, qb, 65536, 200000 + int(qb * 1e5)))
         res["waterfall_seeded_shuffle"] = wf
+        # the layered schedule (the layered_schedule leg's operating point: sweeps on the compressed check state) on the same frames as the flooding points above
+        res["layered_schedule"] = [fer_point(code, enc, args.rule, args.alpha, args.qber, args.fer_frames, 100000, schedule="hlayered")] + \
+                                  [fer_point(code, enc, args.rule, args.alpha, qb, 65536, 200000 + int(qb * 1e5), schedule="hlayered") for qb in (0.0275, 0.03)]
         if args.peg > 0:
             # the same degree profile with the information part grown by progressive edge growth: what the sessions use with peg_depth
             code_p = q.Code.ira_peg(args.n, args.k, 0.125, 11, 3, args.peg, 7)

@@ -319,12 +319,12 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
          * 8 192 .. 65 535 waves; cfg.layer_chain / QLDPC_LAYER_CHAIN = 1 / 0 force it on / off.  (Fewer or more waves in flight per SIMD,
          * QLDPC_CHAIN_WAVES: no difference outside the box-to-box spread, tools/gpu/r3_g47.sh.)  It works on explicit messages: the min-sum rules,
          * which run on the compressed check state below, do not use it. */
-        /* Min-sum sweeps on a compressed check state (qldpc_kernels_cst.h): bit-identical, 0.59 x the bytes on the N = 10^6 code.  fp32 messages,
+        /* Min-sum and AMS sweeps on a compressed check state (qldpc_kernels_cst.h): bit-identical, 0.59 x the bytes on the N = 10^6 code.  fp32 messages,
          * 64-frame groups, messages never frozen, check degree <= 32, and the state must fit the message array.  QLDPC_LAYER_CST = 0 keeps the dc messages. */
         d->layer_cst = 0;
         const char *chain_env = getenv("QLDPC_LAYER_CHAIN");
         const bool chain_asked = chain_env ? atoi(chain_env) != 0 : cfg->layer_chain == 1;      /* an explicit request for the one-launch sweep keeps the explicit messages it works on */
-        if (!chain_asked && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && family_of(cfg->rule) == QK_FAM_MS && d->max_dc <= 32 &&
+        if (!chain_asked && !d->msg_i8 && !d->msg_half && d->V == 1 && !d->freeze && (family_of(cfg->rule) == QK_FAM_MS || family_of(cfg->rule) == QK_FAM_AMS) && d->max_dc <= 32 &&
             (size_t)d->M * 1024 <= (size_t)d->E * 256)
             d->layer_cst = 1;
         if (const char *e = getenv("QLDPC_LAYER_CST")) d->layer_cst = d->layer_cst && atoi(e) != 0;

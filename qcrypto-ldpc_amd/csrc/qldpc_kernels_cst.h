@@ -3,8 +3,8 @@
  *
  * In the layered schedule (Decoder_LDPC_BP_horizontal_layered::_decode_single_ite; ML/BPSK_nrldpc_sim.m:29-69 is the same
  * recursion) a check's dc messages are private to that check: written at the end of its update, read back at the start of its
- * next one, by nobody else.  For the min-sum family (MS / OMS / NMS: tools::Update_rule_{MS,OMS,NMS}) those dc floats per frame
- * take only two magnitudes,
+ * next one, by nobody else.  For the min-sum family (MS / OMS / NMS: tools::Update_rule_{MS,OMS,NMS}) and the AMS rules
+ * (tools::Update_rule_AMS: |contribution_k| == min ? delta_min : delta) those dc floats per frame take only two magnitudes,
  *     messages[k] = +-( |contribution_k| == min1 ? cst1 : cst2 ),
  * so the check keeps, per frame, {cst1, cst2} and two dc-bit masks -- bit k of `took1`: edge k took cst1; bit k of `neg`: the
  * message of edge k is negative -- i.e. FOUR 256-byte rows per check and 64-frame group instead of dc, and rebuilds the very
@@ -37,7 +37,20 @@ __device__ __forceinline__ float qk_cst_msg(uint32_t neg, uint32_t took1, int k,
     return qk_withsign(((took1 >> k) & 1u) ? c1 : c2, (neg >> k) << 31);
 }
 
-template <int DCMAX>
+/* the two magnitudes of a finished check and the test that tells which one an edge took, per rule family */
+template <int FAM> struct qk_cst_of;
+template <> struct qk_cst_of<QK_FAM_MS> {
+    static __device__ __forceinline__ float c1(const qk_acc<QK_FAM_MS> &a) { return a.cst1; }
+    static __device__ __forceinline__ float c2(const qk_acc<QK_FAM_MS> &a) { return a.cst2; }
+    static __device__ __forceinline__ bool took1(const qk_acc<QK_FAM_MS> &a, float x) { return fabsf(x) == a.min1; }
+};
+template <> struct qk_cst_of<QK_FAM_AMS> {
+    static __device__ __forceinline__ float c1(const qk_acc<QK_FAM_AMS> &a) { return a.delta_min; }
+    static __device__ __forceinline__ float c2(const qk_acc<QK_FAM_AMS> &a) { return a.delta; }
+    static __device__ __forceinline__ bool took1(const qk_acc<QK_FAM_AMS> &a, float x) { return fabsf(x) == a.mn; }
+};
+
+template <int DCMAX, int FAM>
 __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict__ post, float *__restrict__ st,
                                                               const int *__restrict__ list, int n_list,
                                                               const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
@@ -45,6 +58,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
                                                               int first)
 {
     static_assert(DCMAX > 0 && DCMAX <= 32, "one mask bit per edge");
+    static_assert(FAM == QK_FAM_MS || FAM == QK_FAM_AMS, "rules whose messages take two magnitudes per check");
     const int g = blockIdx.y;
     if (qk_group_done<1>(done, g)) return;
     const int lane = threadIdx.x & 63;
@@ -71,12 +85,12 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
         c1 = qk_ldm1(crow); c2 = qk_ldm1(crow + 64);
         neg = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crow + 128)); took1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(crow + 192));
     }
-    qk_acc<QK_FAM_MS> acc;
+    qk_acc<FAM> acc;
     acc.begin();
     if (synd) acc.sign = (uint32_t)((synd[(size_t)g * M + c] >> lane) & 1ull) << 31;
 #pragma unroll
     for (int k = 0; k < DCMAX; k++)
-        if (k < deg) { x[k] = x[k] - qk_cst_msg(neg, took1, k, c1, c2); acc.in(x[k]); }
+        if (k < deg) { x[k] = x[k] - qk_cst_msg(neg, took1, k, c1, c2); qk_acc_in<FAM>(acc, x[k], rule); }
     acc.finish(rule);
     neg = 0u; took1 = 0u;
 #pragma unroll
@@ -85,10 +99,10 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
             const float o = acc.out(x[k], rule);
             pg[(size_t)vn[k] * 64] = x[k] + o;      /* posteriors are re-read by later layers: cached */
             neg |= (qk_bits(o) >> 31) << k;
-            took1 |= (fabsf(x[k]) == acc.min1 ? 1u : 0u) << k;
+            took1 |= (qk_cst_of<FAM>::took1(acc, x[k]) ? 1u : 0u) << k;
         }
-    __builtin_nontemporal_store(acc.cst1, crow);
-    __builtin_nontemporal_store(acc.cst2, crow + 64);
+    __builtin_nontemporal_store(qk_cst_of<FAM>::c1(acc), crow);
+    __builtin_nontemporal_store(qk_cst_of<FAM>::c2(acc), crow + 64);
     __builtin_nontemporal_store(neg, reinterpret_cast<uint32_t *>(crow + 128));
     __builtin_nontemporal_store(took1, reinterpret_cast<uint32_t *>(crow + 192));
 }

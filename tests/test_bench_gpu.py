@@ -57,6 +57,9 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one()
     h = fd["headline_qber"]
     assert h["frames"] >= 1 << 20 and h["qber"] == 0.02 and h["undetected_errors"] == 0 and h["frame_errors"] <= 2
     assert 0.0 < h["fer_upper_95"] < 1e-5 and 9 < h["avg_iterations"] < 14 and h["max_iterations"] <= 50
+    hl = fd["layered_schedule"]      # the same frames through the layered sweeps: no worse than flooding, half the iterations
+    assert hl[0]["frames"] >= 1 << 20 and hl[0]["frame_errors"] <= 2 and hl[0]["undetected_errors"] == 0 and hl[0]["avg_iterations"] < 0.6 * h["avg_iterations"]
+    assert all(p_["undetected_errors"] == 0 for p_ in hl)
     wf = fd["waterfall_seeded_shuffle"]
     assert len(wf) == 8 and all(p_["frames"] == 65536 and p_["undetected_errors"] == 0 for p_ in wf)
     assert wf[0]["fer"] < 0.01 < wf[3]["fer"]              # NMS: clean at 2.5 %, inside the waterfall at 3.25 %

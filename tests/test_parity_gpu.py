@@ -564,10 +564,10 @@ def test_one_launch_layered_sweep_is_bit_exact(q, O, torch, peg, rule, param, fr
             assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all()     # bit-exact floats
 
 
-@pytest.mark.parametrize("rule,param", EXACT[:3])
+@pytest.mark.parametrize("rule,param", EXACT)
 @pytest.mark.parametrize("frames", [3, 64, 130])
 def test_layered_min_sum_on_the_compressed_check_state_is_bit_exact(q, O, torch, monkeypatch, rule, param, frames):
-    """Round 3 (qldpc_kernels_cst.h): layered MS / OMS / NMS sweeps keep {cst1, cst2} and two dc-bit masks per check and frame instead of the dc
+    """Round 3 (qldpc_kernels_cst.h): layered MS / OMS / NMS / AMS sweeps keep {cst1, cst2} and two dc-bit masks per check and frame instead of the dc
     messages and rebuild each message from them.  Same floats in, same floats out: hard decisions, iteration counts, success flags and (fixed
     iterations) posteriors must be those of the oracle, with the state on (the default for these rules) and with explicit messages
     (QLDPC_LAYER_CST = 0), on an irregular code whose checks fall into several degree buckets; and the syndrome (coset) form through load_bits."""
