@@ -161,7 +161,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
     for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t); (void)hipFree(d->d_vn_tr);
-    (void)hipFree(d->d_last_mask); (void)hipFree(d->d_chain_order); (void)hipFree(d->d_chain_dep); (void)hipFree(d->d_chain_ver); (void)hipFree(d->d_chain_ctl);
+    (void)hipFree(d->d_chain_order); (void)hipFree(d->d_chain_dep); (void)hipFree(d->d_chain_ver); (void)hipFree(d->d_chain_ctl);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
     (void)hipFree(d->d_sgn); if (d->d_hard != d->d_sgn) (void)hipFree(d->d_hard); (void)hipFree(d->d_unsat); (void)hipFree(d->d_done);
     (void)hipFree(d->d_depth); (void)hipFree(d->d_iters); (void)hipFree(d->d_active); (void)hipFree(d->h_in); (void)hipFree(d->h_out); (void)hipFree(d->d_synd); (void)hipFree(d->e_synd);
@@ -328,24 +328,6 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
             (size_t)d->M * 1024 <= (size_t)d->E * 256)
             d->layer_cst = 1;
         if (const char *e = getenv("QLDPC_LAYER_CST")) d->layer_cst = d->layer_cst && atoi(e) != 0;
-        if (d->layer_cst) {
-            /* bit k of last_mask[c]: edge k of check c is the last update its VN gets in a sweep (layers in their order; inside a layer no VN is shared) -- the
-             * wave that makes it writes the VN's posterior ballots (qk_cn_layer_cst).  Every VN needs a check for that: a code with an isolated VN keeps the separate pass. */
-            std::vector<int> last_edge((size_t)d->N, -1), lmask((size_t)d->M, 0);
-            for (int i = 0; i < d->M; i++) {
-                const int c = code->layer_order[i];
-                for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++) last_edge[(size_t)code->cn_var[k]] = k;
-            }
-            bool every_vn = true;
-            for (int v = 0; v < d->N; v++) every_vn = every_vn && last_edge[(size_t)v] >= 0;
-            if (every_vn && !getenv("QLDPC_LAYER_BALLOT_PASS")) {
-                for (int c = 0; c < d->M; c++)
-                    for (int k = code->cn_ptr[c]; k < code->cn_ptr[c + 1]; k++)
-                        if (last_edge[(size_t)code->cn_var[k]] == k) lmask[(size_t)c] = (int)((unsigned)lmask[(size_t)c] | (1u << (k - code->cn_ptr[c])));
-                if ((rc = dev_alloc(d, &d->d_last_mask, (size_t)d->M))) return rc;
-                HIPCHK(hipMemcpy(d->d_last_mask, lmask.data(), sizeof(int) * (size_t)d->M, hipMemcpyHostToDevice));
-            }
-        }
         d->chain = 0;
         {
             const long per_layer = (long)d->M / std::max(1, code->n_layers) * d->G;
@@ -839,13 +821,11 @@ static int run_layered(qldpc_decoder *d)
         if (d->msg_i8) hipLaunchKernelGGL(qi_post_ballots, dim3((unsigned)bx_of(d), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, (const uint32_t *)d->d_a, d->d_sgn, (u64 *)nullptr, d->N, d->d_done);
         else hipLaunchKernelGGL((qk_post_ballots<V>), dim3((unsigned)std::max(1, std::min((d->N + 32 * QK_WAVES - 1) / (32 * QK_WAVES), 8192 / std::max(1, d->G))), (unsigned)d->G), dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_sgn, d->d_hard, d->N, d->d_done);
     };
-    const bool fused_ballots = d->layer_cst && d->d_last_mask != nullptr && !chain;
     int ite = 0;
     for (; ite < n_ite; ite++) {
         {
             prof_scope ps(d, KS_LAYER, bytes_layer(d), moved_layer(d));
             d->layer_first = (skip_clear && ite == 0) ? 1 : 0;
-            d->layer_ballots = (fused_ballots && (d->cfg.enable_syndrome || ite == n_ite - 1)) ? 1 : 0;      /* the sweeps whose ballots somebody reads */
             if (chain) {
                 HIPCHK(hipMemsetAsync(d->d_chain_ctl + QC_CTL_SHARD0, 0, sizeof(int) * 32 * QC_SHARDS, d->stream));      /* the ticket counters; the fault word stays */
                 qldpc_launch_layer_chain(d, ite);
@@ -856,7 +836,7 @@ static int run_layered(qldpc_decoder *d)
                     for (auto &b : d->layer_buckets[(size_t)l]) { qldpc_launch_layer<V>(d, b); LAUNCHCHK(); }
         }
         if (d->cfg.enable_syndrome) {
-            if (!fused_ballots) {
+            {
                 prof_scope ps(d, KS_SYND, 0.0, (double)d->N * 4.0 * d->n_frames);      /* the sign ballots of the posteriors: N rows read */
                 ballots();
                 LAUNCHCHK();
@@ -871,7 +851,8 @@ static int run_layered(qldpc_decoder *d)
         }
     }
     d->last_iters = std::min(ite, n_ite);
-    if (!fused_ballots || n_ite == 0) { ballots(); LAUNCHCHK(); }      /* (a compressed-state sweep wrote them itself) */
+    ballots();
+    LAUNCHCHK();
     if (chain) {
         /* a wait that ran into its bound left the fault word set: the decode cannot be trusted; say so and go back to a launch per layer */
         int ctl[4] = {0, 0, 0, 0};

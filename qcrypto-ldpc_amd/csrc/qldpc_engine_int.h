@@ -62,7 +62,6 @@ struct qldpc_decoder {
     int n_layers;
     /* one launch per sweep for small batches (qldpc_kernels_chain.h): execution order, per-edge {dv, rank}, per-VN version counters, ticket / fault words */
     int layer_cst;      /* layered min-sum keeps {cst1, cst2} per check and two ballot words per edge instead of dc messages (qldpc_kernels_cst.h) */
-    int *d_last_mask; int layer_ballots;      /* compressed-state sweeps: per check, the edges that are their VN's last update of a sweep; this sweep writes the posterior ballots itself */
     int chain, chain_blocks, chain_lds; int *d_chain_order, *d_chain_dep, *d_chain_ver, *d_chain_ctl; int chain_sweeps;
     int layer_first;                 /* layered fp32 run, sweep 0, messages not frozen: the layer kernels treat the messages as zero instead of reading a cleared array */
     /* state */

@@ -23,13 +23,6 @@
  * The state lives in the message array the decoder owns anyway ([G][E][64] floats per group): rows of check c at c * 256
  * floats -- {cst1, cst2, neg, took1}[64]; M * 1024 <= E * 256 bytes is checked by the host, check degree <= 32.
  * Sweep 0 takes the state as zero (messages +0.0) without reading it, as qk_cn_layer does.  freeze_messages = 0 only.
- *
- * The sign ballots of the posteriors (what check_syndrome_soft tests after a sweep, and what decode_siho outputs) are written by the sweep
- * itself: the host marks, per check, the edges that are the LAST update of their variable node in the sweep's order (bit k of last_mask[c]);
- * the wave that makes that update ballots the posterior it stores and lane k writes the two words of VN k.  The separate pass over the
- * posterior array (N rows read per sweep) is not run any more.  Measured (same-box A/B, QLDPC_LAYER_BALLOT_PASS = 1 brings the pass back): the 2 N scattered
- * 8-byte stores cost the sweep almost what the pass cost -- N = 10^6 code, 64 frames: sweep 559 -> 613 us, ballots + syndrome 80 -> 24 us per sweep, early
- * exit 11.7 -> 11.9 Gbit/s; the headline code on the layered schedule 13.4 -> 13.8 Gbit/s: +2 .. 4 %, one launch fewer per sweep.
  */
 #ifndef QLDPC_KERNELS_CST_H
 #define QLDPC_KERNELS_CST_H
@@ -62,8 +55,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
                                                               const int *__restrict__ list, int n_list,
                                                               const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
                                                               int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, const u64 *__restrict__ synd, int M,
-                                                              int first, const uint32_t *__restrict__ last_mask /* or NULL: no ballots from this sweep */,
-                                                              u64 *__restrict__ sgn, u64 *__restrict__ hard)
+                                                              int first)
 {
     static_assert(DCMAX > 0 && DCMAX <= 32, "one mask bit per edge");
     static_assert(FAM == QK_FAM_MS || FAM == QK_FAM_AMS, "rules whose messages take two magnitudes per check");
@@ -87,9 +79,6 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
 #pragma unroll
     for (int k = 0; k < DCMAX; k++)
         if (k < deg) x[k] = pg[(size_t)vn[k] * 64];
-    const uint32_t lm = last_mask ? last_mask[c] : 0u;      /* wave-uniform */
-    int my_vn = 0;
-    if (lm && lane < deg) my_vn = cn_var[b + lane];        /* lane k looks after the ballot words of the check's k-th VN */
     float c1 = 0.0f, c2 = 0.0f;
     uint32_t neg = 0u, took1 = 0u;
     if (!first) {
@@ -104,28 +93,14 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
         if (k < deg) { x[k] = x[k] - qk_cst_msg(neg, took1, k, c1, c2); qk_acc_in<FAM>(acc, x[k], rule); }
     acc.finish(rule);
     neg = 0u; took1 = 0u;
-    uint32_t slo = 0u, shi = 0u, hlo = 0u, hhi = 0u;
 #pragma unroll
     for (int k = 0; k < DCMAX; k++)
         if (k < deg) {
             const float o = acc.out(x[k], rule);
-            const float p = x[k] + o;
-            pg[(size_t)vn[k] * 64] = p;      /* posteriors are re-read by later layers: cached */
+            pg[(size_t)vn[k] * 64] = x[k] + o;      /* posteriors are re-read by later layers: cached */
             neg |= (qk_bits(o) >> 31) << k;
             took1 |= (qk_cst_of<FAM>::took1(acc, x[k]) ? 1u : 0u) << k;
-            if ((lm >> k) & 1u) {      /* wave-uniform: nobody updates this VN again in this sweep */
-                const u64 s = __ballot((qk_bits(p) >> 31) != 0u), h = __ballot(!(p >= 0.0f));
-                slo = qk_wlane(slo, (uint32_t)s, k); shi = qk_wlane(shi, (uint32_t)(s >> 32), k);
-                hlo = qk_wlane(hlo, (uint32_t)h, k); hhi = qk_wlane(hhi, (uint32_t)(h >> 32), k);
-            }
         }
-    if (lane < deg && ((lm >> lane) & 1u)) {
-        u64 s = ((u64)shi << 32) | slo, h = ((u64)hhi << 32) | hlo;
-        const size_t bi = (size_t)g * N + my_vn;
-        const u64 dm = done[g];      /* converged frames keep the ballots they converged with */
-        if (dm) { s = (s & ~dm) | (sgn[bi] & dm); h = (h & ~dm) | (hard[bi] & dm); }
-        sgn[bi] = s; hard[bi] = h;
-    }
     __builtin_nontemporal_store(qk_cst_of<FAM>::c1(acc), crow);
     __builtin_nontemporal_store(qk_cst_of<FAM>::c2(acc), crow + 64);
     __builtin_nontemporal_store(neg, reinterpret_cast<uint32_t *>(crow + 128));
