@@ -101,6 +101,138 @@ void qldpc_code_free(qldpc_code *c)
  * a greedy colouring, which is the sequential sweep of a row-permuted H (order exported through
  * qldpc_code_layer_order so a reference decoder can be given the same row order).
  */
+/*
+ * DSATUR colouring of the check-conflict graph (two checks conflict when they share a VN), at most 64 colours: the uncoloured check whose VNs
+ * already carry the most distinct colours goes next (ties: the larger conflict degree, then the lower index) and takes the lowest colour none of
+ * its VNs carries.  A check's forbidden set is the OR of its VNs' used-colour words, its saturation the popcount of that; a bucket queue by
+ * saturation holds the uncoloured checks.  On the IRA codes of the bench (conflict degree ~ 78, largest VN degree 11) first-fit in index order needs
+ * 30 classes with a long tail of small ones (10 756 ... 283, 26 checks at N = 10^6); DSATUR needs 24, of which 22 hold 5 700 - 10 300 checks
+ * (tools/dsatur_probe.c; iterated-greedy passes on top do not get below 24).  Fewer, fuller layer launches per sweep.  Returns the number of
+ * colours with lvl[c] = colour + 1, or 0 when 64 colours do not suffice / memory runs out (the caller then colours first-fit).
+ */
+static int dsatur_cmp(const void *a, const void *b)      /* keys carry their check's index: no state outside the array (codes are built on several threads) */
+{
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static int colour_dsatur(const qldpc_code *g, int *lvl)
+{
+    const int N = g->N, M = g->M;
+    uint64_t *used = (uint64_t *)calloc((size_t)N, sizeof(uint64_t));
+    int *sat = (int *)calloc((size_t)M, sizeof(int)), *nxt = (int *)malloc(sizeof(int) * (size_t)M), *prv = (int *)malloc(sizeof(int) * (size_t)M);
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)M);
+    int k = 0, head[65];
+    if (!used || !sat || !nxt || !prv || !keys) { k = -1; goto out; }
+    for (int c = 0; c < M; c++) {
+        uint64_t d = 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) d += (uint64_t)(g->vn_ptr[g->cn_var[j] + 1] - g->vn_ptr[g->cn_var[j]] - 1);
+        keys[c] = (d << 32) | (uint64_t)(0xffffffffu - (uint32_t)c);      /* conflict degree, then the index (descending) */
+        lvl[c] = 0;
+    }
+    qsort(keys, (size_t)M, sizeof(uint64_t), dsatur_cmp);      /* ascending: pushed to the front one by one, the largest degree (lowest index among equals) ends up first */
+    for (int s = 0; s < 65; s++) head[s] = -1;
+    for (int i = 0; i < M; i++) { const int c = (int)(0xffffffffu - (uint32_t)(keys[i] & 0xffffffffu)); nxt[c] = head[0]; prv[c] = -1; if (head[0] >= 0) prv[head[0]] = c; head[0] = c; }
+    for (int done = 0; done < M; done++) {
+        int s = 64;
+        while (s > 0 && head[s] < 0) s--;
+        const int c = head[s];
+        if (c < 0) { k = 0; goto out; }      /* cannot happen: every uncoloured check sits in a bucket */
+        head[s] = nxt[c];
+        if (nxt[c] >= 0) prv[nxt[c]] = -1;
+        uint64_t forb = 0;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) forb |= used[g->cn_var[j]];
+        if (!~forb) { k = 0; goto out; }      /* a 65th colour: not for this routine */
+        const int q = __builtin_ctzll(~forb);
+        lvl[c] = q + 1;
+        if (q + 1 > k) k = q + 1;
+        for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) {
+            const int v = g->cn_var[j];
+            if ((used[v] >> q) & 1ull) continue;
+            used[v] |= 1ull << q;
+            for (int t = g->vn_ptr[v]; t < g->vn_ptr[v + 1]; t++) {
+                const int d = g->vn_chk[t];
+                if (lvl[d]) continue;
+                uint64_t f = 0;
+                for (int jj = g->cn_ptr[d]; jj < g->cn_ptr[d + 1]; jj++) f |= used[g->cn_var[jj]];
+                const int ns = __builtin_popcountll(f);
+                if (ns != sat[d]) {
+                    if (prv[d] >= 0) nxt[prv[d]] = nxt[d]; else head[sat[d]] = nxt[d];
+                    if (nxt[d] >= 0) prv[nxt[d]] = prv[d];
+                    nxt[d] = head[ns]; prv[d] = -1;
+                    if (head[ns] >= 0) prv[head[ns]] = d;
+                    head[ns] = d;
+                    sat[d] = ns;
+                }
+            }
+        }
+    }
+out:
+    free(used); free(sat); free(nxt); free(prv); free(keys);
+    return k > 0 ? k : 0;
+}
+
+/* colours (bit q = colour q + 1 of lvl) carried by the checks on c's VNs, c itself and `skip` left out */
+static uint64_t colours_around(const qldpc_code *g, const int *lvl, int c, int skip)
+{
+    uint64_t f = 0;
+    for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1]; j++) {
+        const int v = g->cn_var[j];
+        for (int t = g->vn_ptr[v]; t < g->vn_ptr[v + 1]; t++) {
+            const int d = g->vn_chk[t];
+            if (d != c && d != skip && lvl[d]) f |= 1ull << (lvl[d] - 1);
+        }
+    }
+    return f;
+}
+/*
+ * DSATUR leaves a last class of a handful of checks (23 of 200 000 at N = 10^6, 1 of 13 107 at N = 65 536): a launch of its own per sweep for nothing.
+ * Each of its checks c is moved into a class q where it conflicts with at most three checks, after each of those has moved to another class that none of
+ * its neighbours (c included, at its new colour) carries.  Returns the new number of classes (k - 1 if the class could be emptied, else k with lvl untouched).
+ */
+static int dissolve_last_class(const qldpc_code *g, int *lvl, int k)
+{
+    const int M = g->M;
+    int n_last = 0;
+    for (int c = 0; c < M; c++) n_last += lvl[c] == k;
+    if (k < 3 || k > 64 || n_last == 0 || n_last > 256) return k;
+    int *saved = (int *)malloc(sizeof(int) * (size_t)M);
+    if (!saved) return k;
+    memcpy(saved, lvl, sizeof(int) * (size_t)M);
+    for (int c = 0; c < M; c++) {
+        if (lvl[c] != k) continue;
+        int moved = 0;
+        for (int q = 0; q < k - 1 && !moved; q++) {
+            /* the checks of class q + 1 that share a VN with c: up to three of them may be moved out of the way */
+            int blk[3], cnt = 0;
+            for (int j = g->cn_ptr[c]; j < g->cn_ptr[c + 1] && cnt <= 3; j++) {
+                const int v = g->cn_var[j];
+                for (int t = g->vn_ptr[v]; t < g->vn_ptr[v + 1]; t++) {
+                    const int d = g->vn_chk[t];
+                    if (d == c || lvl[d] != q + 1) continue;
+                    int seen = 0;
+                    for (int i = 0; i < cnt && i < 3; i++) seen |= blk[i] == d;
+                    if (!seen) { if (cnt < 3) blk[cnt] = d; cnt++; }
+                }
+            }
+            if (cnt > 3) continue;
+            int old[3], ok = 1;
+            for (int i = 0; i < cnt && ok; i++) {
+                old[i] = lvl[blk[i]];
+                uint64_t f = colours_around(g, lvl, blk[i], c) | (1ull << q) | (1ull << (k - 1));      /* c will carry q; the class being dissolved is not a target */
+                if (k - 1 < 64) f |= ~0ull << (k - 1);
+                if (!~f) { for (int u = 0; u < i; u++) lvl[blk[u]] = old[u]; ok = 0; break; }
+                lvl[blk[i]] = __builtin_ctzll(~f) + 1;      /* (the next blocker sees this one at its new colour) */
+            }
+            if (!ok) continue;
+            lvl[c] = q + 1;
+            moved = 1;
+        }
+        if (!moved) { memcpy(lvl, saved, sizeof(int) * (size_t)M); free(saved); return k; }
+    }
+    free(saved);
+    return k - 1;
+}
+
 static int build_layers(qldpc_code *g)
 {
     const int N = g->N, M = g->M;
@@ -117,7 +249,13 @@ static int build_layers(qldpc_code *g)
         if (l > nlev) nlev = l;
     }
     g->layer_natural = 1;
-    if (nlev > 256 && nlev > M / 16) {
+    int dsat = 0;
+    if (nlev > 256 && nlev > M / 16 && !getenv("QLDPC_FIRST_FIT_LAYERS") && (dsat = colour_dsatur(g, lvl)) > 0) {
+        for (int again = 1; again; ) { const int k2 = dissolve_last_class(g, lvl, dsat); again = k2 < dsat; dsat = k2; }
+        nlev = dsat;
+        g->layer_natural = 0;
+    }
+    if (!dsat && nlev > 256 && nlev > M / 16) {
         /* greedy colouring, first-fit, with a per-VN bitset of used colours */
         int words = 4;
         uint64_t *used = (uint64_t *)calloc((size_t)N * words, sizeof(uint64_t));
