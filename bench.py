@@ -444,6 +444,18 @@ def main():
             torch.cuda.empty_cache()
         res["workload"] = "N=%d K=%d IRA LDPC (E=%d, %d colour layers), horizontal-layered NMS(%.2f), <= %d sweeps, syndrome test every sweep, QBER %.1f %%, %d frames" % (
             n5, k5, code5.E, code5.n_layers, args.alpha, args.n_ite, args.qber * 100, f5)
+        # HBM traffic of one sweep from the committed PMC summary of this workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected;
+        # tools/gpu/r3_profiles2.sh): a constant read from profiles/, labelled as such -- per sweep = per-launch bytes of the layer kernels x launches per sweep
+        try:
+            pmc5 = json.load(open(os.path.join(ROOT, "profiles", "r03_config5_cst_pmc_hbm_traffic.json")))
+            lk = {k_: v_ for k_, v_ in pmc5["kernels"].items() if k_.startswith("qk_cn_layer_cst")}
+            if lk and f5 == pmc5["workload"]["frames"] and cst5:
+                per_sweep = sum(v_["hbm_bytes_corrected"] * v_["launches"] for v_ in lk.values()) / (sum(v_["launches"] for v_ in lk.values()) / code5.n_layers)
+                for name in ("fixed", "early_exit"):
+                    res[name]["roofline"]["traffic"] = per_sweep
+                    res[name]["roofline"]["traffic_source"] = "profiles/r03_config5_cst_pmc_hbm_traffic.json (" + pmc5["source"].split(" -- ", 1)[-1] + ")"
+        except Exception as ex:      # noqa: BLE001
+            log("no PMC traffic file for config 5: %s" % ex)
         res["roofline_note"] = ("frac prices SURVEY 8(d)'s algorithmic bytes (4 E message / posterior rows per sweep) against the measured sweep time; the min-sum sweep keeps a compressed "
                                 "check state and MOVES 2 E + 8 M rows (0.61 of them on this code), so frac can pass 1 on full launches -- moved_frac is the share of the HBM peak actually used")
         return res

@@ -17,3 +17,6 @@ python3 tools/pmc_summary.py $O/config5_fetch $O/config5_write $O/r03_config5_cs
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
 du -sh $O; ls $O; cat $O/pmc_summary.txt | grep -i "layer\|ballot\|synd"
+# the default bench line of the same tree
+cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python3 bench.py 2> $O/bench_default.err > $O/bench_default.json; echo "bench rc=$?"
