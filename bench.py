@@ -462,14 +462,14 @@ def main():
 
     # ---- BASELINE config 3: multi-rate H set {0.5, 0.7, 0.8, 0.9} chosen per epoch from the estimated QBER, a stream of epochs through
     #      the reconciliation sessions (what the ecd2 handlers call), HOST buffers in and out ----------------------------------------
-    def config3(peg_depth=2, rate_gap=None, gap_profile=0):
+    def config3(peg_depth=2, rate_gap=None, gap_profile=0, schedule="auto"):
         epochs_n, key_bits, batch = 512, 52429, 512      # every rate group of the stream is one batch of its decoder
         rng = np.random.default_rng(42)
         qbers = rng.uniform(0.005, 0.06, epochs_n).astype(np.float32)
         alice = rng.integers(0, 2, (epochs_n, key_bits)).astype(np.uint8)
         bob = alice ^ (rng.random((epochs_n, key_bits)) < qbers[:, None])
         aw, bw = q.pack_bits(alice), q.pack_bits(bob)
-        kw = dict(device=local_rank, max_blocks=batch, peg_depth=peg_depth, rate_gap=rate_gap, gap_profile=gap_profile)
+        kw = dict(device=local_rank, max_blocks=batch, peg_depth=peg_depth, rate_gap=rate_gap, gap_profile=gap_profile, schedule=schedule)
         ra, rb = q.Recon(**kw), q.Recon(**kw)
         keys = [aw[i] for i in range(epochs_n)]
         ra.encode_blocks(keys, [key_bits] * epochs_n, qbers)                  # builds the codes of the table (warm-up)
@@ -513,7 +513,8 @@ def main():
                 ok[i] = True
         leak = int(leaked[ok].sum())
         kern_ms = sum(s_["total_ms"] for s_ in ks.values())
-        hot = [ks[k_] for k_ in ("cn_update", "vn_update") if k_ in ks]
+        hot = [ks[k_] for k_ in ("cn_update", "vn_update", "layer_update") if k_ in ks and ks[k_]["launches"]]
+        layered3 = "layer_update" in ks and ks["layer_update"]["launches"] > 0
         hot_bytes = sum(s_["alg_bytes"] for s_ in hot)
         return dict(value=float(epochs_n - first_fail) * key_bits / dt3 / 1e6, unit="Mbit/s of sifted key, host buffers in and out (PCIe, CRC and packing included)",
                     fer=float(first_fail) / epochs_n, fer_after_second_round=float(1.0 - ok.mean()), undetected_errors=undetected,
@@ -525,13 +526,16 @@ def main():
                     wall_frac=hot_bytes / dt3 / 1e9 / HBM_PEAK_GBS,
                     # the rate groups run side by side on their own streams, so per-launch event times overlap and their sum says nothing about the device:
                     # this roofline prices the check + variable passes' SURVEY 8d bytes against the WALL time of the call (= wall_frac)
-                    roofline=dict(bound="hbm", kernel="qk_cn_flood + qk_vn_flood of the session decoders (SPA, early exit, batches of <= %d blocks, rate groups side by side)" % batch,
+                    roofline=dict(bound="hbm", kernel=("qk_cn_layer sweeps" if layered3 else "qk_cn_flood + qk_vn_flood") + " of the session decoders (SPA, early exit, batches of <= %d blocks, rate groups side by side)" % batch,
                                   peak=HBM_PEAK_GBS, unit="GB/s", alg_bytes=hot_bytes, moved_bytes=sum(s_["moved_bytes"] for s_ in hot),
                                   achieved=hot_bytes / dt3 / 1e9, frac=hot_bytes / dt3 / 1e9 / HBM_PEAK_GBS, against="wall time of the decode_blocks call (copies, staging, verification included)",
                                   summed_kernel_ms=sum(s_["total_ms"] for s_ in hot), summed_all_kernels_ms=kern_ms,
                                   note="summed_*_ms add per-launch event times of kernels that overlap on the device: they exceed ms_total and are not a duration"),
                     workload="%d epochs x %d bits, QBER ~ U[0.5 %%, 6 %%] (seed 42), rate per epoch from {0.5, 0.7, 0.8, 0.9} (f = 1.4), mother code K = 57344 (%s) shortened + punctured per epoch, "
-                             "flooding SPA, one decode_blocks call for the stream, gap profile %d" % (epochs_n, key_bits, "PEG depth %d" % peg_depth if peg_depth else "seeded shuffle", gap_profile))
+                             "%s SPA, one decode_blocks call for the stream, gap profile %d" % (epochs_n, key_bits, "PEG depth %d" % peg_depth if peg_depth else "seeded shuffle",
+                                                                                                  "horizontal-layered" if layered3 else "flooding", gap_profile),
+                    schedule_note="the sessions decode batches on the horizontal-layered schedule (qldpc_recon_cfg.schedule = auto): about half as many passes over the same bytes per pass as flooding, "
+                                  "so wall_frac (section 8(d) bytes of the passes executed / wall time / 8 TB/s) is lower at a higher throughput; flooding_schedule is the same stream on round 2's schedule")
 
     cfg3 = cfg5 = ferd = None
     if rank == 0 and world == 1 and args.schedule == "flooding" and args.msg_dtype == "f32" and (N, K) == (65536, 52429):
@@ -551,6 +555,8 @@ def main():
             cfg3["peg_mothers_round2_gaps"] = {k_: fast[k_] for k_ in keep}
             shuf = config3(peg_depth=0)        # round 2's codes and gaps: the seeded socket shuffle, for comparison
             cfg3["seeded_shuffle_mothers"] = {k_: shuf[k_] for k_ in keep}
+            flood = config3(schedule="flooding")      # the default's codes and gaps on the flooding schedule (the sessions' schedule until this round)
+            cfg3["flooding_schedule"] = {k_: flood[k_] for k_ in keep}
         if not args.no_fer_deep:
             ferd = fer_deep()
 

@@ -75,6 +75,7 @@ typedef enum qldpc_rule {
 typedef enum qldpc_schedule {
     QLDPC_SCHED_FLOODING = 0,
     QLDPC_SCHED_HLAYERED = 1      /* horizontal layered, checks visited in the code's layer order */
+#define QLDPC_RECON_SCHED_AUTO 2  /* qldpc_recon_cfg.schedule only: chosen by the batch size of the session's decoders */
 } qldpc_schedule;
 
 /*
@@ -329,8 +330,10 @@ typedef struct qldpc_recon_cfg {
     int key_quantum;       /* 1024 (multiple of 32)                                              */
     int max_blocks;        /* blocks decoded concurrently by qldpc_recon_decode_batch            */
     uint64_t seed;         /* IRA construction seed shared by both sides (7)                     */
-    int schedule;          /* qldpc_schedule of Bob's decoder: FLOODING (default) or HLAYERED (about half the
-                              iterations; batches only -- the one-block edge engine is flooding)           */
+    int schedule;          /* schedule of Bob's decoder: QLDPC_RECON_SCHED_AUTO (default) = horizontal layered when the decoders take
+                              batches (max_blocks > 8: half the iterations for the same bytes per sweep; config-3 stream 16.1 -> 14.4 ms,
+                              0 instead of 0 - 1 first-round failures in 2 048 epochs), flooding for max_blocks <= 8 (the one-block
+                              edge-parallel engine is flooding); QLDPC_SCHED_FLOODING / QLDPC_SCHED_HLAYERED force one */
     int mother_step;       /* 8192: blocks of up to mother_max bits use mother codes whose K is a multiple of this (a block
                               is shortened to its length per frame), so a handful of codes serve every block; 0 = a code per size */
     int mother_max;        /* 65536 */

@@ -574,7 +574,7 @@ class Recon:
     """One side's reconciliation engine: what an ecd2 LDPC handler calls (qber_estim.c:337-340,420-423)."""
 
     def __init__(self, device=0, efficiency=1.4, rates=(0.5, 0.7, 0.8, 0.9), n_ite=None, rule=None, rule_param=None,
-                 key_quantum=1024, max_blocks=1, seed=7, schedule="flooding", mother_step=None, mother_max=None, rate_gap=None,
+                 key_quantum=1024, max_blocks=1, seed=7, schedule="auto", mother_step=None, mother_max=None, rate_gap=None,
                  puncture=True, preload=False, peg_depth=None, gap_profile=0):
         cfg = ReconCfg()
         _L.qldpc_recon_cfg_default(C.byref(cfg))
@@ -586,7 +586,7 @@ class Recon:
         if rule is not None:
             cfg.rule, cfg.rule_param = RULES[rule], float(rule_param or 0.0)
         cfg.key_quantum, cfg.max_blocks, cfg.seed = int(key_quantum), int(max_blocks), int(seed)
-        cfg.schedule = SCHEDULES[schedule]
+        cfg.schedule = 2 if schedule == "auto" else SCHEDULES[schedule]      # QLDPC_RECON_SCHED_AUTO: layered for batches (max_blocks > 8), flooding (edge engine) below
         if mother_step is not None:
             cfg.mother_step = int(mother_step)
         if mother_max is not None:

@@ -7,7 +7,7 @@
  *   epochs x key_bits sifted bits, QBER per epoch ~ U[qmin, qmax] (what the daemon would have estimated), Bob's copy = Alice's
  *   through a BSC of that QBER; reconciled = status OK and Bob's words == Alice's.
  *
- * usage: qldpc_stream [-e epochs] [-k key_bits] [-b max_blocks] [-S seed] [-r reps] [-q qmin:qmax] [-l (layered)] [-P depth (PEG mothers)]
+ * usage: qldpc_stream [-e epochs] [-k key_bits] [-b max_blocks] [-S seed] [-r reps] [-q qmin:qmax] [-l (layered) | -f (flooding); default: the sessions' choice = layered for batches] [-P depth (PEG mothers)]
  *                     [-g rate_gap] [-G gap_profile] [-p (per-kernel profile of Bob's decoders in a second pass)]
  *                     (defaults: 512 epochs x 52 429 bits, max_blocks 512, PEG depth 2 = the library's default)
  * prints one JSON object on stdout.
@@ -56,10 +56,10 @@ static void *part_main(void *arg)
 
 int main(int argc, char **argv)
 {
-    int epochs = 512, key_bits = 52429, batch = 512, reps = 3, layered = 0, profile = 0, peg = 2, opt, a_lanes = 0, b_lanes = 0, verbose = 0, split = 1, gap_profile = 0;
+    int epochs = 512, key_bits = 52429, batch = 512, reps = 3, layered = -1, profile = 0, peg = 2, opt, a_lanes = 0, b_lanes = 0, verbose = 0, split = 1, gap_profile = 0;
     uint64_t seed = 42;
     double qmin = 0.005, qmax = 0.06, gap = 0.0;
-    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lpP:g:A:B:vT:G:")) != -1) {
+    while ((opt = getopt(argc, argv, "e:k:b:S:r:q:lfpP:g:A:B:vT:G:")) != -1) {
         switch (opt) {
         case 'e': epochs = atoi(optarg); break;
         case 'k': key_bits = atoi(optarg); break;
@@ -68,6 +68,7 @@ int main(int argc, char **argv)
         case 'r': reps = atoi(optarg); break;
         case 'q': if (sscanf(optarg, "%lf:%lf", &qmin, &qmax) != 2) { fprintf(stderr, "-q qmin:qmax\n"); return 2; } break;
         case 'l': layered = 1; break;
+        case 'f': layered = 0; break;
         case 'p': profile = 1; break;
         case 'P': peg = atoi(optarg); break;
         case 'g': gap = atof(optarg); break;
@@ -97,7 +98,8 @@ int main(int argc, char **argv)
     qldpc_recon_cfg cfg;
     qldpc_recon_cfg_default(&cfg);
     cfg.max_blocks = batch;
-    cfg.schedule = layered ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING;
+    if (layered >= 0) cfg.schedule = layered ? QLDPC_SCHED_HLAYERED : QLDPC_SCHED_FLOODING;      /* else the default: layered for batches of more than 8 blocks */
+    else layered = batch > 8;
     cfg.rate_gap = (float)gap;
     cfg.peg_depth = peg;
     cfg.gap_profile = gap_profile;

@@ -108,4 +108,8 @@ def test_config3_stream_timed_from_c():
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["reconciled"] == d["epochs"] == 96 and sum(d["epochs_per_rate"]) == 96 and sum(1 for x in d["epochs_per_rate"] if x) >= 3
     assert 0.25 < d["leaked_fraction"] < 0.36 and d["failed_per_rate"] == [0, 0, 0, 0]
-    assert d["ms_best"] > 0 and d["kernels"]["cn_update"]["launches"] > 0
+    assert d["ms_best"] > 0 and d["kernels"]["layer_update"]["launches"] > 0 and "cn_update" not in d["kernels"]      # batches decode on the layered schedule by default
+    p = subprocess.run([exe, "-e", "96", "-k", "20011", "-b", "64", "-r", "2", "-S", "5", "-p", "-f"], capture_output=True, text=True, timeout=300)      # -f: flooding, round 2's schedule
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    f = json.loads(p.stdout.strip().splitlines()[-1])
+    assert f["reconciled"] == 96 and f["kernels"]["cn_update"]["launches"] > 0 and f["leaked_fraction"] == d["leaked_fraction"] and f["avg_iterations"] > 1.5 * d["avg_iterations"]

@@ -153,7 +153,8 @@ def test_blocks_of_mixed_length_and_plan_in_one_call(q, max_blocks):
     spec = [(14500, 0.015), (14900, 0.015), (15000, 0.016), (14337, 0.014),      # one code: K = 16 384, rate 0.8; four lengths, three puncturings
             (15000, 0.05), (14800, 0.048),                                         # rate 0.5 plan
             (3000, 0.02), (64000, 0.01), (15100, 0.015), (14999, 0.015), (15360, 0.015)]
-    batch, single = q.Recon(max_blocks=max_blocks), q.Recon(max_blocks=1)
+    # (both on the flooding schedule: iteration counts are compared; the sessions' default puts batches of more than 8 blocks on the layered schedule -- last lines)
+    batch, single = q.Recon(max_blocks=max_blocks, schedule="flooding"), q.Recon(max_blocks=1)
     keys, bobs, msgs, pars = [], [], [], []
     for kb, p in spec:
         a, b, _ = block(q, rng, kb, p)
@@ -176,6 +177,11 @@ def test_blocks_of_mixed_length_and_plan_in_one_call(q, max_blocks):
         else:
             assert i == 2 and (fixed[i] == bobs[i]).all()                           # untouched
     assert (st == 0).sum() == len(spec) - 1
+    # the default schedule of the same session size (layered above 8 blocks per call): the same verdicts, keys and corrected-bit counts, in fewer passes
+    st2, fixed2, co2, it2 = q.Recon(max_blocks=max_blocks).decode_blocks(bobs, [s[0] for s in spec], [s[1] for s in spec], msgs, pars)
+    assert (np.asarray(st2) == np.asarray(st)).all() and all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(fixed2, fixed)) and (np.asarray(co2) == np.asarray(co)).all()
+    it2, it, okm = np.asarray(it2), np.asarray(it), np.asarray(st) == 0
+    assert (it2 == it).all() if max_blocks <= 8 else it2[okm].sum() < 0.75 * it[okm].sum()
 
 
 def test_mother_codes_are_preloaded_and_nothing_is_built_afterwards(q):
