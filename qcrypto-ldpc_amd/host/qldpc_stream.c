@@ -214,8 +214,11 @@ int main(int argc, char **argv)
             if (status[e] == QLDPC_OK && !memcmp(work + (size_t)e * W, alice + (size_t)e * W, (size_t)W * 4)) { good++; leaked += qldpc_recon_leaked_bits(&msgs[e]); }
         }
     }
-    int per_rate[8] = {0}, fail_rate[8] = {0}, maxed[8] = {0};
+    int per_rate[8] = {0}, fail_rate[8] = {0}, maxed[8] = {0}, it_max[8] = {0};
+    double it_mean[8] = {0};
     for (int e = 0; e < epochs; e++) {
+        if (iters[e] > it_max[msgs[e].rate_index & 7]) it_max[msgs[e].rate_index & 7] = iters[e];
+        it_mean[msgs[e].rate_index & 7] += iters[e];
         per_rate[msgs[e].rate_index & 7]++;
         if (!(status[e] == QLDPC_OK && !memcmp(work + (size_t)e * W, alice + (size_t)e * W, (size_t)W * 4))) fail_rate[msgs[e].rate_index & 7]++;
         if (iters[e] >= cfg.n_ite) maxed[msgs[e].rate_index & 7]++;
@@ -224,10 +227,11 @@ int main(int argc, char **argv)
     printf("{\"workload\": \"%d epochs x %d bits, QBER ~ U[%.3f, %.3f] seed %llu, batches of <= %d blocks, %s, one decode_blocks call\", "
            "\"reconciled\": %d, \"epochs\": %d, \"ms_mean\": %.3f, \"ms_best\": %.3f, \"Mbit_s_mean\": %.1f, \"Mbit_s_best\": %.1f, "
            "\"leaked_fraction\": %.4f, \"avg_iterations\": %.2f, \"alice_encode_ms\": %.3f, \"epochs_per_rate\": [%d, %d, %d, %d], \"failed_per_rate\": [%d, %d, %d, %d], "
-           "\"at_max_iterations_per_rate\": [%d, %d, %d, %d]",
+           "\"at_max_iterations_per_rate\": [%d, %d, %d, %d], \"mean_iterations_per_rate\": [%.1f, %.1f, %.1f, %.1f], \"max_iterations_per_rate\": [%d, %d, %d, %d]",
            epochs, key_bits, qmin, qmax, (unsigned long long)seed, batch, layered ? "layered" : "flooding", good, epochs, mean * 1e3, best * 1e3,
            (double)good * key_bits / mean / 1e6, (double)good * key_bits / best / 1e6, (double)leaked / fmax(1.0, (double)good * key_bits), it_sum / epochs,
-           t_enc * 1e3, per_rate[0], per_rate[1], per_rate[2], per_rate[3], fail_rate[0], fail_rate[1], fail_rate[2], fail_rate[3], maxed[0], maxed[1], maxed[2], maxed[3]);
+           t_enc * 1e3, per_rate[0], per_rate[1], per_rate[2], per_rate[3], fail_rate[0], fail_rate[1], fail_rate[2], fail_rate[3], maxed[0], maxed[1], maxed[2], maxed[3],
+           it_mean[0] / fmax(1, per_rate[0]), it_mean[1] / fmax(1, per_rate[1]), it_mean[2] / fmax(1, per_rate[2]), it_mean[3] / fmax(1, per_rate[3]), it_max[0], it_max[1], it_max[2], it_max[3]);
     if (profile) {
         qldpc_kernel_stat st[16];
         qldpc_recon_profile_enable(rb, 1);
