@@ -162,6 +162,41 @@ def test_layer_order_is_a_valid_schedule(q, gold):
                     last[v] = m
 
 
+def test_colour_classes_by_dsatur_are_fewer_fuller_and_thread_safe(q, monkeypatch):
+    """Round 3: when the natural order has no parallelism (IRA: the dual-diagonal chain) the layers are colour classes of the check-conflict graph, coloured by
+    DSATUR instead of first-fit in index order: fewer classes, none of them a handful of checks, still VN-disjoint; the same code built on several threads at
+    once (as qldpc_recon_create(preload) does) gets the same order as built alone -- the routine keeps no state outside its arrays."""
+    import threading
+
+    def layers(code):
+        order, ptr, natural = code.layer_order()
+        assert not natural and sorted(order.tolist()) == list(range(code.M))
+        var, chk = code.edges()
+        lay = np.empty(code.M, np.int64)
+        for l in range(code.n_layers):
+            lay[order[ptr[l]:ptr[l + 1]]] = l
+        key = var.astype(np.int64) * 4096 + lay[chk]
+        assert len(np.unique(key)) == len(key)          # no VN twice in one layer
+        return order.copy(), np.diff(ptr)
+
+    order, sizes = layers(q.Code.ira(65536, 52429, 0.125, 11, 3, 7))
+    assert len(sizes) <= 24 and sizes.min() >= 64 and sizes[:20].min() > 400      # first-fit: 30 classes, the last five of 166, 109, 63, 15 and 5 checks
+    monkeypatch.setenv("QLDPC_FIRST_FIT_LAYERS", "1")
+    _, sizes_ff = layers(q.Code.ira(65536, 52429, 0.125, 11, 3, 7))
+    monkeypatch.delenv("QLDPC_FIRST_FIT_LAYERS")
+    assert len(sizes_ff) == 30 and sizes_ff.min() < 16
+    got = [None] * 6
+
+    def build(i):
+        got[i] = q.Code.ira(65536, 52429, 0.125, 11, 3, 7).layer_order()[0].copy() if i % 2 == 0 else q.Code.ira(16384, 13107, 0.125, 11, 3, 7).layer_order()[0].copy()
+    th = [threading.Thread(target=build, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all((got[i] == order).all() for i in (0, 2, 4)) and (got[1] == got[3]).all() and (got[3] == got[5]).all()
+
+
 def test_qc_natural_layers_are_block_rows(q, gold):
     c = q.Code.from_qc(os.path.join(gold, "NR_2_3_112.qc"))     # 42 block rows, Z = 112
     _, _, natural = c.layer_order()
