@@ -33,7 +33,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.gpu
-def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one():
+def test_default_bench_line_covers_configs_2_3_5_and_every_moved_frac_is_at_most_one():
     """one default run puts BASELINE configs 2 (the line itself), 3 and 5 in front of the driver, each with its own roofline,
     moved bytes beside algorithmic bytes, and no fraction above 1 (round 1's layered mode summed one pass three times)."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=1500)
@@ -68,5 +68,7 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_frac_is_at_most_one()
     assert c5["fixed"]["roofline"]["moved_bytes_per_sweep"] < 0.7 * c5["fixed"]["roofline"]["alg_bytes_per_sweep"] and "compressed" in c5["fixed"]["roofline"]["kernel"]
     ls = d["layered_schedule"]      # the headline code and batch on AFF3CT's other schedule
     assert ls["fixed"]["fer"] == 0.0 and ls["early_exit"]["fer"] == 0.0 and ls["fixed"]["value"] > d["value"] and ls["early_exit"]["value"] > e["value"] and ls["early_exit"]["avg_sweeps"] < 8
-    fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["frac"], c5["early_exit"]["roofline"]["frac"], c5["fixed"]["roofline"]["moved_frac"], ls["fixed"]["roofline_moved_frac"]]
+    # (config 5's frac prices section 8(d)'s 4 E rows per sweep against a kernel that moves 0.61 of them: it sits at 0.93 - 0.97 and may pass 1 on a fast box; what is bounded by 1 is the moved share)
+    assert 0.5 < c5["fixed"]["roofline"]["frac"] < 1.0 / 0.6 and abs(c5["fixed"]["roofline"]["moved_frac"] / c5["fixed"]["roofline"]["frac"] - c5["fixed"]["roofline"]["moved_bytes_per_sweep"] / c5["fixed"]["roofline"]["alg_bytes_per_sweep"]) < 1e-6
+    fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["moved_frac"], c5["early_exit"]["roofline"]["moved_frac"], ls["fixed"]["roofline_moved_frac"]]
     assert all(0.0 < f <= 1.0 for f in fracs), fracs
