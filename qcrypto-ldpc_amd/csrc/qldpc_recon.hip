@@ -79,17 +79,20 @@ struct qldpc_recon {
 
 static const uint32_t *crc_table()
 {
-    static uint32_t t[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; i++) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; k++) c = (c & 1) ? CRC_POLY ^ (c >> 1) : c >> 1;
-            t[i] = c;
+    /* built once behind the compiler's guard of a function-local static: the lanes' host workers may get here together */
+    struct table {
+        uint32_t t[256];
+        table()
+        {
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; k++) c = (c & 1) ? CRC_POLY ^ (c >> 1) : c >> 1;
+                t[i] = c;
+            }
         }
-        init = true;
-    }
-    return t;
+    };
+    static const table tab;
+    return tab.t;
 }
 
 /* CRC-32 (IEEE 802.3) over the key bits, fed MSB-first word by word, bits past n_bits masked to 0 */
@@ -526,12 +529,12 @@ static float clamp_qber(float q) { return !(q > 0.001f) ? 0.001f : (q > 0.25f ? 
  */
 static double gap_scale(const qldpc_recon_cfg &cfg, double R, int K)
 {
-    static double env[3] = {-2.0, 0.0, 0.0};
-    if (env[0] < -1.5) {
+    struct from_env {      /* read once, behind the guard of a function-local static (sessions may plan on several threads) */
         double v[3] = {-1.0, -1.0, -1.0};
-        if (const char *e = getenv("QLDPC_RECON_GAP_SCALE")) (void)sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]);
-        env[1] = v[1]; env[2] = v[2]; env[0] = v[0];
-    }
+        from_env() { if (const char *e = getenv("QLDPC_RECON_GAP_SCALE")) (void)sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]); }
+    };
+    static const from_env env_scale;
+    const double *env = env_scale.v;
     const int k = R <= 0.75 ? 0 : (R <= 0.85 ? 1 : 2);
     if (env[0] >= 0.0 && env[k] >= 0.0) return env[k];
     static const double peg[3] = {0.10, 0.85, 1.0}, shuffle[3] = {0.60, 0.90, 1.0};
