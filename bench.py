@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-message-storage variant leg")
     ap.add_argument("--no-layered", action="store_true", help="skip the horizontal-layered leg on the headline code")
     ap.add_argument("--no-int8", action="store_true", help="skip the 8-bit fixed-point variant leg")
+    ap.add_argument("--no-spa", action="store_true", help="skip the flooding-SPA leg on the headline code (the harness's default rule)")
     ap.add_argument("--no-fer-deep", action="store_true", help="skip the deep frame-error-rate leg (>= 2^20 frames at the headline QBER + waterfall points)")
     ap.add_argument("--fer-frames", type=int, default=1 << 20, help="frames of the deep FER point at the headline QBER")
     ap.add_argument("--peg", type=int, default=2, help="PEG depth of the second code the FER / config-3 legs report beside the seeded shuffle (0 = skip)")
@@ -189,9 +190,9 @@ def main():
     if rank == 0:
         log("frames ready: %d per GPU (%.1f s), code N=%d K=%d M=%d E=%d" % (F, time.time() - t0, N, K, code.M, code.E))
 
-    def make_decoder(enable_syndrome, msg_dtype=None, schedule=None):
+    def make_decoder(enable_syndrome, msg_dtype=None, schedule=None, rule=None):
         msg_dtype = msg_dtype or args.msg_dtype
-        d = q.Decoder(code, K, args.n_ite, rule=args.rule, rule_param=args.alpha, enable_syndrome=enable_syndrome,
+        d = q.Decoder(code, K, args.n_ite, rule=rule or args.rule, rule_param=args.alpha if rule is None else 0.0, enable_syndrome=enable_syndrome,
                       n_frames=F, device=local_rank, frames_per_lane=args.frames_per_lane, msg_dtype=msg_dtype, schedule=schedule or args.schedule)
         d.set_stream(torch.cuda.current_stream(device))
         return d
@@ -283,10 +284,10 @@ def main():
     # f16: messages rounded to binary16 in HBM, fp32 arithmetic.  i8: 8-bit fixed-point min-sum (quantiser 8 steps per LLR
     # unit, messages saturating at +-127).  Both are FER-tolerance class against the AFF3CT float build and bit-exact
     # against the oracle run with the same arithmetic (tests/test_parity_gpu.py, tests/test_i8_gpu.py).
-    def variant(msg_dtype):
+    def variant(msg_dtype, rule=None):
         res = {}
         for name, synd in (("fixed", False), ("early_exit", True)):
-            dec = make_decoder(synd, msg_dtype)
+            dec = make_decoder(synd, msg_dtype, rule=rule)
             dec.profile(True)
             step(dec)
             dec.profile_clear()
@@ -334,6 +335,16 @@ def main():
 
     fp16 = variant("f16") if not args.no_fp16 else None
     int8 = variant("i8") if (not args.no_int8 and args.rule in ("MS", "OMS", "NMS")) else None
+    # SURVEY 8(d) config 2 names SPA beside NMS: Update_rule_SPA is the harness's default (BS/src/main.cpp:193) and the rule the reference's
+    # published 0.241 Mb/s was measured with.  Same code, frames, schedule and iteration cap as the headline; fp32; tolerance class (one exp,
+    # one rcp and one log per edge on the hardware's transcendental units), so NOT the bit-exact headline.
+    spa = None
+    if not args.no_spa and args.rule != "SPA" and args.schedule == "flooding" and args.msg_dtype == "f32":
+        spa = variant("f32", rule="SPA")
+        for leg in ("fixed", "early_exit"):
+            spa[leg]["cn_update_frac"] = spa[leg]["cn_update_GBs"] / HBM_PEAK_GBS
+        spa["workload"] = "the headline code and batch, flooding SPA (the harness default), fp32, <= %d iterations" % args.n_ite
+        spa["parity_note"] = "tolerance class against the oracle (hardware exp / log / rcp); the oracle's SPA is pinned to AFF3CT by the reference's known-answer vector"
 
     # ---- the FER half of the metric: depth that means something -------------------------------------------------------------------
     # Early-exit mode (AFF3CT's default), fresh seeds per batch.  Per point: frames, frame errors (no valid codeword OR a codeword other
@@ -658,6 +669,7 @@ def main():
             "layered_schedule": lay2,
             "fp16_messages": fp16,
             "int8_messages": int8,
+            "spa_rule": spa,
             "fer_deep": ferd,
             "config3_multirate_stream": cfg3,
             "config5_layered_1e6": cfg5,

@@ -241,7 +241,13 @@ __device__ __forceinline__ float qk_2atanh(float r) { return __logf((1.0f + r) *
  */
 #define QK_SPA_RMAX 16777215.0f      /* (2 - eps) / eps with eps = 2^-23 */
 template <int FAM> __device__ __forceinline__ float qk_prep(float x) { return x; }
-template <> __device__ __forceinline__ float qk_prep<QK_FAM_SPA>(float x) { return qk_withsign(__expf(-fabsf(x)), qk_bits(x)); }
+/* The two transcendentals of the fold as the bare hardware instructions (v_exp_f32 / v_log_f32 work in base 2).  __expf / __logf wrap them in
+ * range handling this rule does not need: exp(-|x|) may flush to 0 below 2^-126 (1 +- e is 1 either way), and the logarithm's argument lies
+ * in [1, QK_SPA_RMAX], never denormal -- 7 VALU instructions fewer per edge of the ~30 the pass spent (ISA: the cmp / cndmask / ldexp / two-term
+ * ln 2 sequences are gone). */
+__device__ __forceinline__ float qk_spa_exp_neg(float a) { return __builtin_amdgcn_exp2f(a * -1.4426950408889634f); }      /* exp(-a), a >= 0 */
+__device__ __forceinline__ float qk_spa_ln(float r) { return __builtin_amdgcn_logf(r) * 0.6931471805599453f; }              /* ln r, 1 <= r < 2^24 */
+template <> __device__ __forceinline__ float qk_prep<QK_FAM_SPA>(float x) { return qk_withsign(qk_spa_exp_neg(fabsf(x)), qk_bits(x)); }
 
 template <> struct qk_acc<QK_FAM_SPA> {
     uint32_t sign; float pnum, pden;
@@ -252,9 +258,11 @@ template <> struct qk_acc<QK_FAM_SPA> {
     {
         const float e = fabsf(xp);
         const float nn = pnum * (1.0f + e), d = pden * (1.0f - e);
-        float r = (d + nn) * qk_rcp(d - nn);
+        /* Nn <= D holds for the exact products; when the other edges' e_j are ~2^-23 the rounded ones can come out an ulp the wrong way round
+         * (the true ratio is then beyond the clamp anyway): |D - Nn| keeps r positive, so the logarithm never sees a negative argument */
+        float r = (d + nn) * qk_rcp(fabsf(d - nn));
         r = (r < QK_SPA_RMAX) ? r : QK_SPA_RMAX;
-        return qk_withsign(__logf(r), sign ^ qk_bits(xp));
+        return qk_withsign(qk_spa_ln(r), sign ^ qk_bits(xp));
     }
 };
 

@@ -30,6 +30,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 0 and d["fer"] < 0.5
     assert d["int8_messages"]["fixed"]["value"] > 0 and d["fp16_messages"]["fixed"]["value"] > 0
     assert "parity unpinned against AFF3CT" in d["parity_note"]
+    assert d["spa_rule"]["fixed"]["value"] > 0 and d["spa_rule"]["early_exit"]["value"] > 0      # "NMS and SPA"
 
 
 @pytest.mark.gpu
@@ -71,4 +72,7 @@ def test_default_bench_line_covers_configs_2_3_5_and_every_moved_frac_is_at_most
     # (config 5's frac prices section 8(d)'s 4 E rows per sweep against a kernel that moves 0.61 of them: it sits at 0.93 - 0.97 and may pass 1 on a fast box; what is bounded by 1 is the moved share)
     assert 0.5 < c5["fixed"]["roofline"]["frac"] < 1.0 / 0.6 and abs(c5["fixed"]["roofline"]["moved_frac"] / c5["fixed"]["roofline"]["frac"] - c5["fixed"]["roofline"]["moved_bytes_per_sweep"] / c5["fixed"]["roofline"]["alg_bytes_per_sweep"]) < 1e-6
     fracs += [c3["roofline"]["frac"], c5["fixed"]["roofline"]["moved_frac"], c5["early_exit"]["roofline"]["moved_frac"], ls["fixed"]["roofline_moved_frac"]]
+    sp = d["spa_rule"]      # SURVEY 8(d) config 2 names SPA beside NMS (the harness default): same code and batch, tolerance class
+    assert sp["fixed"]["fer"] == 0.0 and sp["early_exit"]["fer"] == 0.0 and sp["early_exit"]["avg_iterations"] < e["avg_iterations"] and sp["fixed"]["value"] > 0.6 * d["value"]
+    fracs += [sp["fixed"]["cn_update_frac"]]
     assert all(0.0 < f <= 1.0 for f in fracs), fracs
