@@ -110,7 +110,7 @@ template <typename T> static int dev_alloc(qldpc_decoder *d, T **p, size_t n)
     return QLDPC_OK;
 }
 
-static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_ids, const int *caps, int n_caps, std::vector<bucket> &out)
+static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_ids, const int *caps, int n_caps, std::vector<bucket> &out, const int *var = nullptr)
 {
     std::vector<std::vector<int>> lists(n_caps + 1);
     for (int i = 0; i < n_ids; i++) {
@@ -128,6 +128,20 @@ static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_
         int rc = dev_alloc(d, &bk.d_list, lists[k].size());
         if (rc != QLDPC_OK) return rc;
         HIPCHK(hipMemcpy(bk.d_list, lists[k].data(), lists[k].size() * sizeof(int), hipMemcpyHostToDevice));
+        bk.d_rec = nullptr;
+        if (var && bk.cap > 0) {      /* the list once more as records {id, first edge, degree, 0, var[0 .. cap)} (padding: VN 0, never asked for) */
+            const size_t stride = (size_t)(QK_REC_HDR + bk.cap);
+            std::vector<int> rec(lists[k].size() * stride, 0);
+            for (size_t i = 0; i < lists[k].size(); i++) {
+                const int id = lists[k][i], b = ptr[id], deg = ptr[id + 1] - b;
+                int *r = rec.data() + i * stride;
+                r[0] = id; r[1] = b; r[2] = deg;
+                for (int e = 0; e < deg; e++) r[QK_REC_HDR + e] = var[b + e];
+            }
+            rc = dev_alloc(d, &bk.d_rec, rec.size());
+            if (rc != QLDPC_OK) { (void)hipFree(bk.d_list); return rc; }
+            HIPCHK(hipMemcpy(bk.d_rec, rec.data(), rec.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         out.push_back(bk);
     }
     return QLDPC_OK;
@@ -159,7 +173,7 @@ extern "C" void qldpc_decoder_free(qldpc_decoder *d)
     for (auto &r : d->prof_pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto &b : d->cn_buckets) (void)hipFree(b.d_list);
     for (auto &b : d->vn_buckets) (void)hipFree(b.d_list);
-    for (auto &l : d->layer_buckets) for (auto &b : l) (void)hipFree(b.d_list);
+    for (auto &l : d->layer_buckets) for (auto &b : l) { (void)hipFree(b.d_list); (void)hipFree(b.d_rec); }
     (void)hipFree(d->d_cn_ptr); (void)hipFree(d->d_cn_tr); (void)hipFree(d->d_cn_var); (void)hipFree(d->d_vn_ptr); (void)hipFree(d->d_info_pos); (void)hipFree(d->d_cn_var_t); (void)hipFree(d->d_vn_tr);
     (void)hipFree(d->d_chain_order); (void)hipFree(d->d_chain_dep); (void)hipFree(d->d_chain_ver); (void)hipFree(d->d_chain_ctl);
     (void)hipFree(d->d_llr); (void)hipFree(d->d_llr8); (void)hipFree(d->d_ybits); (void)hipFree(d->d_ebits); (void)hipFree(d->d_fmag); (void)hipFree(d->d_fnch); (void)hipFree(d->d_vcls); (void)hipFree(d->d_a); (void)hipFree(d->d_b); (void)hipFree(d->d_post);
@@ -308,8 +322,11 @@ static int create_impl(const qldpc_code *code, int K, const int *info_bits_pos, 
     } else {
         d->n_layers = code->n_layers;
         d->layer_buckets.resize((size_t)code->n_layers);
+        /* QLDPC_LAYER_REC=0: the layer kernels walk list -> cn_ptr -> cn_var as in rounds 1 - 2 (A/B) */
+        const char *rec_env = getenv("QLDPC_LAYER_REC");
+        const int *rec_var = (rec_env && atoi(rec_env) == 0) ? nullptr : code->cn_var;
         for (int l = 0; l < code->n_layers; l++)
-            if ((rc = make_buckets(d, code->cn_ptr, code->layer_order + code->layer_ptr[l], code->layer_ptr[l + 1] - code->layer_ptr[l], CN_CAPS, 4, d->layer_buckets[(size_t)l]))) return rc;
+            if ((rc = make_buckets(d, code->cn_ptr, code->layer_order + code->layer_ptr[l], code->layer_ptr[l + 1] - code->layer_ptr[l], CN_CAPS, 4, d->layer_buckets[(size_t)l], rec_var))) return rc;
         /* A sweep as ONE launch in which a check waits for the earlier checks on its own VNs instead of for the whole layer before it
          * (qldpc_kernels_chain.h).  fp32 messages, 64-frame groups, messages never frozen, check degree <= 40.  Measured on the N = 10^6 code
          * (fixed 50 sweeps, fraction of the HBM peak, launch per layer -> one launch): 64 frames 0.575 -> 0.566, 128: 0.62 -> 0.68, 256: 0.63 -> 0.71,

@@ -31,7 +31,11 @@ static const char *const ks_names[KS_COUNT] = {"cn_update", "vn_update", "layer_
 
 struct prof_rec { int kind; double bytes, moved; hipEvent_t a, b; };
 
-struct bucket { int cap; int n; int *d_list; };   /* cap = register-resident degree bound, 0 = any degree */
+struct bucket { int cap; int n; int *d_list; int *d_rec; };   /* cap = register-resident degree bound, 0 = any degree */
+/* d_rec (layer buckets with cap > 0, else NULL): entry i of the list as ONE aligned record {check, first edge, degree, 0, vn[0 .. cap)} --
+ * a wave of a layer kernel learns everything it needs to ask for its rows in one scalar round trip instead of three dependent ones
+ * (list -> cn_ptr -> cn_var); the launches of a layered sweep are small and bound by the latency of that chain (DESIGN section 8 #6h);
+ * QK_REC_HDR (qldpc_kernels.h) = 4 header words */
 
 /*
  * Per-frame state of one generation of the early-exit run (qldpc_kernels_compact.h).  Generation 0 is the batch as loaded (its

@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 
 /* rule families (template parameter); the member of the family is a wave-uniform runtime value */
 #define QK_FAM_MS 0           /* MS / OMS / NMS                 */
+#define QK_REC_HDR 4      /* header words of a layer record {check, first edge, degree, 0, vn[...]} (bucket::d_rec, qldpc_engine_int.h) */
 #define QK_FAM_SPA 1
 #define QK_FAM_LSPA 2
 #define QK_FAM_AMS 3          /* AMS<min | min_star_linear2 | min_star> */
@@ -705,23 +706,48 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
                                                           const int *__restrict__ list, int n_list,
                                                           const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
                                                           int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, int freeze, const u64 *__restrict__ synd, int M,
-                                                          int first /* sweep 0: messages are all zero -- they are not read (and the host has not cleared the array) */)
+                                                          int first /* sweep 0: messages are all zero -- they are not read (and the host has not cleared the array) */,
+                                                          const int *__restrict__ rec = nullptr, int rec_stride = 0 /* bucket::d_rec (DCMAX > 0 only) */)
 {
     constexpr int FG = 64 * V;
     const int g = blockIdx.y;
-    if (qk_group_done<V>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = blockIdx.x * QK_WAVES + wave;
     if (i >= n_list) return;
+    /* with records the wave's check, first edge, degree and VNs arrive in one scalar round trip, asked for together with the done words */
+    int c, b, deg;
+    [[maybe_unused]] int rvn[DCMAX > 0 ? DCMAX : 1];
+    bool have_rec = false;
+    if constexpr (DCMAX > 0) {
+        if (rec) {
+            const int *r = static_cast<const int *>(__builtin_assume_aligned(rec + (size_t)i * rec_stride, 16));
+            c = r[0]; b = r[1]; deg = r[2];
+#pragma unroll
+            for (int k = 0; k < DCMAX; k++) rvn[k] = r[QK_REC_HDR + k];
+            have_rec = true;
+            /* keeps the record loads above the early return below (one round trip for the record and the done words together) */
+            u64 dn[V];
+#pragma unroll
+            for (int j = 0; j < V; j++) dn[j] = done[(size_t)g * V + j];
+            asm volatile("" ::"s"(c), "s"(b), "s"(deg), "s"(rvn[0]), "s"(rvn[DCMAX / 2]), "s"(rvn[DCMAX - 1]), "s"(dn[0]), "s"(dn[V - 1]));
+            bool all = true;
+#pragma unroll
+            for (int j = 0; j < V; j++) all = all && dn[j] == ~0ull;
+            if (all) return;
+        }
+    }
+    if (!have_rec) {
+        if (qk_group_done<V>(done, g)) return;
+        c = list[i];
+        b = cn_ptr[c];
+        deg = cn_ptr[c + 1] - b;
+    }
     bool frozen[V];
     const bool any_frozen = qk_frozen<V>(done, g, lane, frozen) && freeze;
     float *pg = post + (size_t)g * N * FG + lane * V;
     float *mg = msg + (size_t)g * group_stride + lane * V;
 
-    const int c = list[i];
-    const int b = cn_ptr[c];
-    const int deg = cn_ptr[c + 1] - b;
     qk_acc<FAM> acc[V];
 #pragma unroll
     for (int j = 0; j < V; j++) {
@@ -732,7 +758,7 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer(float *__restrict__ po
     if constexpr (DCMAX > 0) {
         int vn[DCMAX];
 #pragma unroll
-        for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+        for (int k = 0; k < DCMAX; k++) vn[k] = have_rec ? rvn[k] : cn_var[b + k];
         float x[DCMAX][V], m[DCMAX][V];
 #pragma unroll
         for (int k = 0; k < DCMAX; k++)

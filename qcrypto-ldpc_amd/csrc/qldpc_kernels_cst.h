@@ -55,26 +55,38 @@ __global__ __launch_bounds__(QK_THREADS) void qk_cn_layer_cst(float *__restrict_
                                                               const int *__restrict__ list, int n_list,
                                                               const int *__restrict__ cn_ptr, const int *__restrict__ cn_var,
                                                               int N, size_t group_stride, const u64 *__restrict__ done, qk_rule rule, const u64 *__restrict__ synd, int M,
-                                                              int first)
+                                                              int first, const int *__restrict__ rec, int rec_stride)
 {
     static_assert(DCMAX > 0 && DCMAX <= 32, "one mask bit per edge");
     static_assert(FAM == QK_FAM_MS || FAM == QK_FAM_AMS, "rules whose messages take two magnitudes per check");
     const int g = blockIdx.y;
-    if (qk_group_done<1>(done, g)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = blockIdx.x * QK_WAVES + wave;
     if (i >= n_list) return;
     float *pg = post + (size_t)g * N * 64 + lane;
 
-    const int c = list[i];
-    const int b = cn_ptr[c];
-    const int deg = cn_ptr[c + 1] - b;
-    float *crow = st + (size_t)g * group_stride + (size_t)c * (64 * QK_CST_ROWS) + lane;
-
-    int vn[DCMAX];
+    /* what this wave works on: one aligned record per list entry (bucket::d_rec) asked for together with the group's done word -- one
+     * scalar round trip in front of the row loads instead of done -> list -> cn_ptr -> cn_var */
+    int c, deg, vn[DCMAX];
+    if (rec) {
+        const int *r = static_cast<const int *>(__builtin_assume_aligned(rec + (size_t)i * rec_stride, 16));
+        c = r[0]; deg = r[2];
 #pragma unroll
-    for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+        for (int k = 0; k < DCMAX; k++) vn[k] = r[QK_REC_HDR + k];
+        const u64 dn = done[g];
+        /* keeps the record loads above the early return (the compiler otherwise sinks them behind the done test: two round trips again) */
+        asm volatile("" ::"s"(c), "s"(deg), "s"(vn[0]), "s"(vn[DCMAX / 2]), "s"(vn[DCMAX - 1]), "s"(dn));
+        if (dn == ~0ull) return;
+    } else {
+        if (qk_group_done<1>(done, g)) return;
+        c = list[i];
+        const int b = cn_ptr[c];
+        deg = cn_ptr[c + 1] - b;
+#pragma unroll
+        for (int k = 0; k < DCMAX; k++) vn[k] = cn_var[b + k];
+    }
+    float *crow = st + (size_t)g * group_stride + (size_t)c * (64 * QK_CST_ROWS) + lane;
     float x[DCMAX];
 #pragma unroll
     for (int k = 0; k < DCMAX; k++)

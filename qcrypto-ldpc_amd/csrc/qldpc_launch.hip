@@ -101,11 +101,11 @@ static void launch_layer_one(qldpc_decoder *d, const bucket &b)
     if (d->layer_cst) {      /* min-sum / AMS on the compressed check state (qldpc_kernels_cst.h): the host set this only for V = 1, degrees <= 32 */
         if constexpr (V == 1 && (FAM == QK_FAM_MS || FAM == QK_FAM_AMS) && CAP > 0)
             hipLaunchKernelGGL((qk_cn_layer_cst<(CAP > 32 ? 32 : CAP), FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                               d->N, (size_t)d->E * d->FG, d->d_done, r, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first);
+                               d->N, (size_t)d->E * d->FG, d->d_done, r, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first, b.d_rec, QK_REC_HDR + b.cap);
         return;
     }
     hipLaunchKernelGGL((qk_cn_layer<V, CAP, FAM>), grid, dim3(QK_THREADS), 0, d->stream, d->d_a, d->d_b, b.d_list, b.n, d->d_cn_ptr, d->d_cn_var,
-                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first);
+                       d->N, (size_t)d->E * d->FG, d->d_done, r, d->freeze, d->has_synd ? d->d_synd : nullptr, d->M, d->layer_first, CAP > 0 ? b.d_rec : nullptr, QK_REC_HDR + b.cap);
 }
 template <int V, int FAM>
 static void launch_layer_fam(qldpc_decoder *d, const bucket &b)
