@@ -592,3 +592,28 @@ def test_layered_min_sum_on_the_compressed_check_state_is_bit_exact(q, O, torch,
             lay = {k["name"]: k for k in dec.profile_read()}["layer_update"]
             got[cst] = lay["moved_bytes"] / lay["alg_bytes"]
         assert got["0"] == 1.0 and got["1"] < 0.75      # the state path really ran: 2 E + 8 M rows instead of 4 E
+
+
+@pytest.mark.parametrize("rule,param,cst", [("NMS", 0.75, "1"), ("NMS", 0.75, "0"), ("OMS", 0.25, "0")])
+@pytest.mark.parametrize("frames", [5, 130])
+def test_layer_records_and_the_index_walk_give_the_same_floats(q, O, torch, monkeypatch, rule, param, cst, frames):
+    """Round 3, third session (bucket::d_rec): the layer kernels learn {check, first edge, degree, VNs} from one aligned record per list
+    entry instead of walking list -> cn_ptr -> cn_var.  Only where the indices come from changes: with the records (the default) and with
+    the index walk (QLDPC_LAYER_REC = 0), on the compressed check state and on explicit messages, on a code whose checks fall into several
+    degree buckets (several record strides), hard decisions, iteration counts, success flags and posteriors are the oracle's bit for bit."""
+    code = q.Code.ira(4096, 3277, 0.125, 11, 3, 7)
+    order, _, _ = code.layer_order()
+    var, chk = code.edges()
+    inv = np.empty(code.M, np.int32); inv[order] = np.arange(code.M, dtype=np.int32)
+    og = O.Graph.from_edges(code.N, code.M, *_reorder(var, chk, inv))
+    llr = bsc_frames(np.random.default_rng(170 + frames), frames, code.N, 0.03, 2.9)
+    monkeypatch.setenv("QLDPC_LAYER_CST", cst)
+    for synd in (True, False):
+        ref = O.decode(og, llr, rule, param, 10, "hlayered", synd, 1, n_threads=8)
+        for rec in ("1", "0"):
+            monkeypatch.setenv("QLDPC_LAYER_REC", rec)
+            dec = q.Decoder(code, code.N, 10, rule=rule, rule_param=param, n_frames=frames, schedule="hlayered", enable_syndrome=synd, layer_chain="off")
+            hard, it, ok, post = staged(q, torch, dec, llr, want_post=not synd)
+            assert (hard == ref["hard"]).all() and (it == ref["iters"]).all() and (ok == ref["synd_ok"]).all(), (rec, synd)
+            if not synd:
+                assert (post.view(np.uint32) == ref["post"].view(np.uint32)).all(), rec
