@@ -125,10 +125,11 @@ static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_
         bucket bk;
         bk.cap = k < n_caps ? caps[k] : 0;
         bk.n = (int)lists[k].size();
+        bk.d_rec = nullptr;
         int rc = dev_alloc(d, &bk.d_list, lists[k].size());
         if (rc != QLDPC_OK) return rc;
+        out.push_back(bk);      /* owned by the decoder from here on: an error below leaves nothing behind that decoder_free does not release */
         HIPCHK(hipMemcpy(bk.d_list, lists[k].data(), lists[k].size() * sizeof(int), hipMemcpyHostToDevice));
-        bk.d_rec = nullptr;
         if (var && bk.cap > 0) {      /* the list once more as records {id, first edge, degree, 0, var[0 .. cap)} (padding: VN 0, never asked for) */
             const size_t stride = (size_t)(QK_REC_HDR + bk.cap);
             std::vector<int> rec(lists[k].size() * stride, 0);
@@ -139,10 +140,10 @@ static int make_buckets(qldpc_decoder *d, const int *ptr, const int *ids, int n_
                 for (int e = 0; e < deg; e++) r[QK_REC_HDR + e] = var[b + e];
             }
             rc = dev_alloc(d, &bk.d_rec, rec.size());
-            if (rc != QLDPC_OK) { (void)hipFree(bk.d_list); return rc; }
+            if (rc != QLDPC_OK) return rc;
+            out.back().d_rec = bk.d_rec;
             HIPCHK(hipMemcpy(bk.d_rec, rec.data(), rec.size() * sizeof(int), hipMemcpyHostToDevice));
         }
-        out.push_back(bk);
     }
     return QLDPC_OK;
 }
